@@ -1,0 +1,196 @@
+/* mtgv.h - C ABI of libmtgv.so: the MI355X-native recognition hot path of mtg-vision
+ * (detect -> crop -> embed -> cosine top-k over the card bank).
+ *
+ * Every entry point is what a binding for that path would call.  The reference
+ * (nmichlo/mtg-vision, all paths relative to its root) is pure Python; the
+ * interface each group replaces is cited.  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - return value: 0 = ok, 1 = invalid argument (reference: AssertionError),
+ *     2 = unknown key/name (KeyError), 3 = runtime failure (RuntimeError).
+ *     mtgv_last_error() returns the message of the calling thread's last failure.
+ *   - pointers named *_dev are device (HIP) pointers owned by the caller
+ *     (torch tensors on cuda:<i>); *_host are host pointers.  The library owns
+ *     only weights / bank / workspace inside its opaque handles and allocates
+ *     nothing on the hot path after the first call at a given batch size.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  A handle is
+ *     bound to the HIP device current at creation and is not thread-safe; calls on
+ *     one handle must be serialised by the caller (the reference is single-threaded
+ *     per process: mtgvision/server.py:29-35, :280).
+ *   - activations are float32; images are NHWC unless stated.
+ */
+#ifndef MTGV_H
+#define MTGV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MTGV_API __attribute__((visibility("default")))
+#else
+#define MTGV_API
+#endif
+
+MTGV_API const char* mtgv_last_error(void);
+MTGV_API int mtgv_version(void);
+/* number of HIP devices visible; does not initialise a device context */
+MTGV_API int mtgv_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* Encoder: ConvNeXt-V2 embedding forward.                                    */
+/* Replaces CoreMlEncoder.predict (mtgvision/encoder_export.py:85-110),       */
+/* ConvNeXtV2Encoder.forward (mtgvision/models/convnextv2ae.py:256-266),      */
+/* ConvNeXtV2.forward (mtgvision/models/convnextv2.py:292-303) and            */
+/* MtgVisionEncoder.encode (mtgvision/encoder_train.py:356-358).              */
+/* ------------------------------------------------------------------------- */
+typedef struct mtgv_encoder mtgv_encoder;
+
+enum { MTGV_ENC_AE = 0, MTGV_ENC_PLAIN = 1 };
+enum {
+  MTGV_HEAD_CONV_LINEAR = 0, /* convnextv2ae.py:219-235 */
+  MTGV_HEAD_CONV_MLP = 1,
+  MTGV_HEAD_CONV_ACT_MLP = 2,
+  MTGV_HEAD_POOL_LINEAR = 3, /* convnextv2ae.py:236-248 */
+  MTGV_HEAD_POOL_MLP = 4,
+  MTGV_HEAD_PLAIN = 5        /* GAP -> nn.LayerNorm -> Linear, convnextv2.py:280-303 */
+};
+enum { MTGV_IN_NCHW_F32 = 0, MTGV_IN_NHWC_F32 = 1, MTGV_IN_NHWC_U8 = 2 };
+
+typedef struct {
+  int32_t kind;       /* MTGV_ENC_* */
+  int32_t image_h, image_w;
+  int32_t in_chans;   /* 3 */
+  int32_t z_size;
+  int32_t depths[4];
+  int32_t dims[4];
+  int32_t head_type;  /* MTGV_HEAD_* */
+  int32_t scale_io;   /* x*2-1 first (convnextv2ae.py:257-258) */
+  int32_t max_batch;  /* workspace is sized for this many images */
+} mtgv_encoder_cfg;
+
+MTGV_API int mtgv_encoder_create(const mtgv_encoder_cfg* cfg, mtgv_encoder** out);
+MTGV_API void mtgv_encoder_destroy(mtgv_encoder* h);
+/* Upload one parameter by its reference state_dict key (layout as stored by
+ * PyTorch: conv OIHW, linear [out,in]); numel must match.  Unknown key -> 2. */
+MTGV_API int mtgv_encoder_set_param(mtgv_encoder* h, const char* key, const float* data_host, int64_t numel);
+/* number of parameters still unset (0 = ready) */
+MTGV_API int mtgv_encoder_missing_params(const mtgv_encoder* h);
+/* x_dev: n images in `layout`; z_dev: (n, z_size) float32. */
+MTGV_API int mtgv_encoder_forward(mtgv_encoder* h, const void* x_dev, int32_t layout, int32_t n, float* z_dev, void* stream);
+/* keep a copy of every stage output of subsequent forwards (test/debug aid; off by default) */
+MTGV_API int mtgv_encoder_set_capture(mtgv_encoder* h, int32_t on);
+/* copy stage s (0..3) output of the last forward, NHWC (n, h, w, c), into out_dev; for tests */
+MTGV_API int mtgv_encoder_stage_output(mtgv_encoder* h, int32_t stage, int32_t n, float* out_dev, void* stream);
+/* algorithmic FLOPs (2*MAC) of one image's forward, split MFMA-eligible GEMM / depthwise */
+MTGV_API int mtgv_encoder_flops(const mtgv_encoder* h, double* gemm_flops, double* dw_flops);
+
+/* ------------------------------------------------------------------------- */
+/* Bank: exact cosine top-k over all card vectors.                            */
+/* Replaces VectorStoreQdrant.query_nearby / save_points / retrieve           */
+/* (mtgvision/qdrant.py:17-111; collection "mtg", size 768, Distance.COSINE). */
+/* ------------------------------------------------------------------------- */
+typedef struct mtgv_bank mtgv_bank;
+
+MTGV_API int mtgv_bank_create(int32_t dim, int64_t capacity, mtgv_bank** out);
+MTGV_API void mtgv_bank_destroy(mtgv_bank* h);
+MTGV_API int64_t mtgv_bank_size(const mtgv_bank* h);
+/* append n vectors (device or host memory, is_device says which); stored L2-normalised */
+MTGV_API int mtgv_bank_append(mtgv_bank* h, const float* vecs, int64_t n, int32_t is_device, void* stream);
+/* overwrite row `row` (save_points on an existing id) */
+MTGV_API int mtgv_bank_set_row(mtgv_bank* h, int64_t row, const float* vec_host, void* stream);
+MTGV_API int mtgv_bank_clear(mtgv_bank* h);
+/* copy stored (normalised) rows [row, row+n) to out_host */
+MTGV_API int mtgv_bank_get_rows(const mtgv_bank* h, int64_t row, int64_t n, float* out_host);
+/* q_dev: (b, dim) raw query vectors.  Writes ids (b,k) int64 (row index + id_base, -1 = none)
+ * and scores (b,k) float32, sorted by score desc then id asc. */
+MTGV_API int mtgv_bank_topk(mtgv_bank* h, const float* q_dev, int32_t b, int32_t k, int64_t id_base, int64_t* ids_dev,
+                            float* scores_dev, void* stream);
+/* merge ncand (score,id) candidates per query into the top k (multi-GPU shard merge) */
+MTGV_API int mtgv_topk_merge(float* cand_scores_dev, const int64_t* cand_ids_dev, int32_t b, int32_t ncand, int32_t k,
+                             int64_t* ids_dev, float* scores_dev, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Detector: YOLOv8n-seg forward + decode + NMS + mask logits.                */
+/* Replaces CardSegmenter.__call__ -> ultralytics YOLO predict                */
+/* (mtgvision/od_export.py:141-160; model built in od_train.py:46-70).        */
+/* ------------------------------------------------------------------------- */
+typedef struct mtgv_detector mtgv_detector;
+
+typedef struct {
+  int32_t nc;        /* classes (3: od_train.py:46-50) */
+  int32_t imgsz;     /* 640 */
+  int32_t max_batch;
+  float conf;        /* 0.25 */
+  float iou;         /* 0.7 */
+  int32_t max_det;   /* 300 */
+} mtgv_detector_cfg;
+
+MTGV_API int mtgv_detector_create(const mtgv_detector_cfg* cfg, mtgv_detector** out);
+MTGV_API void mtgv_detector_destroy(mtgv_detector* h);
+/* parameter by ultralytics state_dict key ("model.0.conv.weight", "model.0.bn.running_var", ...) */
+MTGV_API int mtgv_detector_set_param(mtgv_detector* h, const char* key, const float* data_host, int64_t numel);
+MTGV_API int mtgv_detector_missing_params(const mtgv_detector* h);
+/* fold BatchNorm into the conv weights and repack; call once after all params are set */
+MTGV_API int mtgv_detector_finalize(mtgv_detector* h);
+/* frames_dev: (n, imgsz, imgsz, 3) uint8, already letterboxed; flip_rgb reverses the channel
+ * order first (ultralytics treats ndarray input as BGR).
+ * Outputs (device): n_det (n) int32; per frame up to max_det rows of
+ *   boxes (n, max_det, 4) xyxy pixels, conf (n, max_det), cls (n, max_det) int32,
+ *   keep_idx (n, max_det) int32 anchor index in [0, 8400),
+ *   mask_logits (n, max_det, 160, 160) or NULL to skip. */
+MTGV_API int mtgv_detector_forward(mtgv_detector* h, const uint8_t* frames_dev, int32_t n, int32_t flip_rgb,
+                                   int32_t* n_det_dev, float* boxes_dev, float* conf_dev, int32_t* cls_dev,
+                                   int32_t* keep_idx_dev, float* mask_logits_dev, void* stream);
+/* raw head outputs of the last forward: pred (n, 4+nc+32, 8400) and protos (n, 32, 160, 160) */
+MTGV_API int mtgv_detector_raw(mtgv_detector* h, int32_t n, float* pred_dev, float* protos_dev, void* stream);
+MTGV_API int mtgv_detector_flops(const mtgv_detector* h, double* flops_per_frame);
+
+/* NMS alone on decoded predictions pred (n, 4+nc+nm, na) [xywh, class scores, coeffs] */
+MTGV_API int mtgv_nms(const float* pred_dev, int32_t n, int32_t nc, int32_t nm, int32_t na, float conf, float iou,
+                      int32_t max_det, float max_wh, int32_t* n_det_dev, float* boxes_dev, float* conf_dev, int32_t* cls_dev,
+                      int32_t* keep_idx_dev, int32_t* workspace_dev, size_t workspace_bytes, void* stream);
+MTGV_API size_t mtgv_nms_workspace_bytes(int32_t n, int32_t na);
+
+/* ------------------------------------------------------------------------- */
+/* Crop: perspective de-warp of card quads.                                   */
+/* Replaces InstanceSeg.extract_dewarped (mtgvision/od_export.py:95-111).     */
+/* ------------------------------------------------------------------------- */
+/* frames_dev (nf, fh, fw, 3) uint8; quads_dev (nq, 4, 2) float32 source corners (x,y) in the
+ * order dst corners [[0,0],[w,0],[w,h],[0,h]] are matched to; frame_idx_dev (nq) int32.
+ * out_dev (nq, out_h, out_w, 3) uint8. */
+MTGV_API int mtgv_warp_quads(const uint8_t* frames_dev, int32_t nf, int32_t fh, int32_t fw, const float* quads_dev,
+                             const int32_t* frame_idx_dev, int32_t nq, int32_t out_h, int32_t out_w, float expand_ratio,
+                             uint8_t* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Single ops (unit-test and composition surface; same kernels the handles use) */
+/* ------------------------------------------------------------------------- */
+/* out[M,N] = act(A[M,K] W[N,K]^T + bias) (+res);  act: 0 none 1 gelu 2 mish 3 silu 4 sigmoid */
+MTGV_API int mtgv_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
+                            int32_t m, int32_t n, int32_t k, int32_t act, void* stream);
+/* NHWC conv, weight (cout, kh, kw, cin), zero padding */
+MTGV_API int mtgv_op_conv2d(const float* x_dev, const float* w_dev, const float* bias_dev, float* out_dev, int32_t n, int32_t h,
+                            int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                            int32_t act, void* stream);
+MTGV_API int mtgv_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* out_dev, int64_t rows,
+                               int32_t c, float eps, void* stream);
+/* depthwise 7x7 pad 3; weight (49, c) tap-major */
+MTGV_API int mtgv_op_dwconv7(const float* x_dev, const float* w49_dev, const float* bias_dev, float* out_dev, int32_t n,
+                             int32_t h, int32_t w, int32_t c, void* stream);
+/* one ConvNeXt-V2 block on NHWC x (n,h,w,c): convnextv2.py:212-224.  params in reference layout
+ * except dw weight (49,c).  ws_dev: workspace of mtgv_op_block_workspace_floats() floats. */
+MTGV_API int mtgv_op_block(const float* x_dev, float* out_dev, int32_t n, int32_t h, int32_t w, int32_t c, int32_t act,
+                           const float* dw_w49, const float* dw_b, const float* ln_w, const float* ln_b, const float* w1,
+                           const float* b1, const float* gamma, const float* beta, const float* w2, const float* b2,
+                           float* ws_dev, void* stream);
+MTGV_API int64_t mtgv_op_block_workspace_floats(int32_t n, int32_t h, int32_t w, int32_t c);
+MTGV_API int mtgv_op_l2norm(const float* x_dev, float* out_dev, int64_t rows, int32_t d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTGV_H */

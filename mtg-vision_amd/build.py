@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Build libmtgv.so (HIP kernels + C-ABI, gfx950 only) in-tree.
+
+    python mtg-vision_amd/build.py [--force] [--jobs N]
+
+Each csrc/*.hip|*.cpp is compiled to build/<name>.o with hipcc (cross-compiles
+without a GPU) and linked into mtgv/libmtgv.so.  Objects are rebuilt only when
+a source or header is newer.
+"""
+
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "mtgv", "libmtgv.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-fvisibility=hidden",
+    "-I",
+    os.path.join(ROOT, "include"),
+    "-I",
+    CSRC,
+    "-Wno-unused-result",
+]
+
+
+def _newest_header() -> float:
+    t = 0.0
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                t = max(t, os.path.getmtime(os.path.join(d, f)))
+    return t
+
+
+def build(force: bool = False, jobs: int = 6, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+    hdr_t = _newest_header()
+    todo = []
+    objs = []
+    for f in srcs:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, os.path.splitext(f)[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            todo.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[mtgv build] {os.path.basename(src)}", flush=True)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+            list(ex.map(cc, todo))
+    if todo or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[mtgv build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=6)
+    a = ap.parse_args()
+    print(build(a.force, a.jobs))

@@ -1,0 +1,198 @@
+// C ABI (include/mtgv.h): encoder, bank and single-op entry points.
+// Detector / NMS / warp entry points live next to their kernels (detector.hip, nms.hip, warp.hip).
+#include "mtgv.h"
+
+#include "encoder.h"
+#include "match.h"
+#include "rowops.h"
+
+namespace mtgv {
+const char* last_error_cstr();
+}
+
+using namespace mtgv;
+
+struct mtgv_encoder {
+  Encoder impl;
+  explicit mtgv_encoder(const mtgv_encoder_cfg& c) : impl(c) {}
+};
+struct mtgv_bank {
+  Bank impl;
+  mtgv_bank(int d, int64_t c) : impl(d, c) {}
+};
+
+extern "C" {
+
+MTGV_API const char* mtgv_last_error(void) { return last_error_cstr(); }
+MTGV_API int mtgv_version(void) { return 100; }
+MTGV_API int mtgv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---- encoder ----
+MTGV_API int mtgv_encoder_create(const mtgv_encoder_cfg* cfg, mtgv_encoder** out) {
+  return guarded([&] {
+    MTGV_CHECK(cfg != nullptr && out != nullptr, ERR_INVALID, "null argument");
+    *out = new mtgv_encoder(*cfg);
+  });
+}
+MTGV_API void mtgv_encoder_destroy(mtgv_encoder* h) { delete h; }
+MTGV_API int mtgv_encoder_set_param(mtgv_encoder* h, const char* key, const float* data_host, int64_t numel) {
+  return guarded([&] {
+    MTGV_CHECK(h && key && data_host, ERR_INVALID, "null argument");
+    h->impl.set_param(key, data_host, numel);
+  });
+}
+MTGV_API int mtgv_encoder_missing_params(const mtgv_encoder* h) { return h ? h->impl.missing() : -1; }
+MTGV_API int mtgv_encoder_forward(mtgv_encoder* h, const void* x_dev, int32_t layout, int32_t n, float* z_dev, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
+    h->impl.forward(x_dev, layout, n, z_dev, (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_encoder_set_capture(mtgv_encoder* h, int32_t on) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
+    h->impl.set_capture(on != 0);
+  });
+}
+MTGV_API int mtgv_encoder_stage_output(mtgv_encoder* h, int32_t stage, int32_t n, float* out_dev, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr && out_dev != nullptr, ERR_INVALID, "null argument");
+    h->impl.stage_output(stage, n, out_dev, (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_encoder_flops(const mtgv_encoder* h, double* gemm_flops, double* dw_flops) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
+    h->impl.flops(gemm_flops, dw_flops);
+  });
+}
+
+// ---- bank ----
+MTGV_API int mtgv_bank_create(int32_t dim, int64_t capacity, mtgv_bank** out) {
+  return guarded([&] {
+    MTGV_CHECK(out != nullptr, ERR_INVALID, "null argument");
+    *out = new mtgv_bank(dim, capacity);
+  });
+}
+MTGV_API void mtgv_bank_destroy(mtgv_bank* h) { delete h; }
+MTGV_API int64_t mtgv_bank_size(const mtgv_bank* h) { return h ? h->impl.size() : -1; }
+MTGV_API int mtgv_bank_append(mtgv_bank* h, const float* vecs, int64_t n, int32_t is_device, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr && (vecs != nullptr || n == 0), ERR_INVALID, "null argument");
+    h->impl.append(vecs, n, is_device != 0, (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_bank_set_row(mtgv_bank* h, int64_t row, const float* vec_host, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr && vec_host != nullptr, ERR_INVALID, "null argument");
+    h->impl.set_row(row, vec_host, (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_bank_clear(mtgv_bank* h) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
+    h->impl.clear();
+  });
+}
+MTGV_API int mtgv_bank_get_rows(const mtgv_bank* h, int64_t row, int64_t n, float* out_host) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr && (out_host != nullptr || n == 0), ERR_INVALID, "null argument");
+    h->impl.get_rows(row, n, out_host);
+  });
+}
+MTGV_API int mtgv_bank_topk(mtgv_bank* h, const float* q_dev, int32_t b, int32_t k, int64_t id_base, int64_t* ids_dev,
+                            float* scores_dev, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
+    h->impl.topk(q_dev, b, k, id_base, ids_dev, scores_dev, (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_topk_merge(float* cand_scores_dev, const int64_t* cand_ids_dev, int32_t b, int32_t ncand, int32_t k,
+                             int64_t* ids_dev, float* scores_dev, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(cand_scores_dev && cand_ids_dev && ids_dev && scores_dev, ERR_INVALID, "null argument");
+    topk_merge_launch_i64(cand_scores_dev, cand_ids_dev, b, ncand, k, ids_dev, scores_dev, (hipStream_t)stream);
+  });
+}
+
+// ---- single ops ----
+MTGV_API int mtgv_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
+                            int32_t m, int32_t n, int32_t k, int32_t act, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(a_dev && w_dev && out_dev, ERR_INVALID, "null argument");
+    GemmArgs g = linear_args(a_dev, k, w_dev, bias_dev, out_dev, n, m, n, k, act);
+    g.res = res_dev;
+    g.ldr = n;
+    gemm_launch(g, gemm_plan(m, n, k), (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_op_conv2d(const float* x_dev, const float* w_dev, const float* bias_dev, float* out_dev, int32_t n, int32_t h,
+                            int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                            int32_t act, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(x_dev && w_dev && out_dev, ERR_INVALID, "null argument");
+    MTGV_CHECK(stride > 0 && kh > 0 && kw > 0 && pad >= 0, ERR_INVALID, "bad conv geometry");
+    const int oh = (h + 2 * pad - kh) / stride + 1, ow = (w + 2 * pad - kw) / stride + 1;
+    MTGV_CHECK(oh > 0 && ow > 0, ERR_INVALID, "empty conv output");
+    GemmArgs g;
+    g.A = x_dev, g.W = w_dev, g.bias = bias_dev, g.Out = out_dev;
+    g.M = n * oh * ow, g.N = cout, g.K = kh * kw * cin;
+    g.H = h, g.Wd = w, g.c_total = cin, g.Cin = cin;
+    g.KH = kh, g.KW = kw, g.stride = stride, g.pad = pad;
+    g.OH = oh, g.OW = ow, g.OH2 = oh, g.OW2 = ow;
+    g.ldo = cout;
+    g.act = act;
+    gemm_launch(g, gemm_plan(g.M, g.N, g.K), (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* out_dev, int64_t rows,
+                               int32_t c, float eps, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(x_dev && w_dev && b_dev && out_dev, ERR_INVALID, "null argument");
+    ln_rows_launch(x_dev, c, 0, out_dev, c, 0, w_dev, b_dev, rows, c, eps, (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_op_dwconv7(const float* x_dev, const float* w49_dev, const float* bias_dev, float* out_dev, int32_t n,
+                             int32_t h, int32_t w, int32_t c, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(x_dev && w49_dev && bias_dev && out_dev, ERR_INVALID, "null argument");
+    dwconv7_launch(x_dev, w49_dev, bias_dev, out_dev, n, h, w, c, (hipStream_t)stream);
+  });
+}
+MTGV_API int64_t mtgv_op_block_workspace_floats(int32_t n, int32_t h, int32_t w, int32_t c) {
+  if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return 0;
+  return (int64_t)block_ws_size(n, h, w, c).total();
+}
+MTGV_API int mtgv_op_block(const float* x_dev, float* out_dev, int32_t n, int32_t h, int32_t w, int32_t c, int32_t act,
+                           const float* dw_w49, const float* dw_b, const float* ln_w, const float* ln_b, const float* w1,
+                           const float* b1, const float* gamma, const float* beta, const float* w2, const float* b2,
+                           float* ws_dev, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(x_dev && out_dev && ws_dev && x_dev != out_dev, ERR_INVALID, "null or aliased tensor");
+    MTGV_CHECK(c % 4 == 0, ERR_INVALID, "block: C=%d must be a multiple of 4", c);
+    BlockW bw;
+    bw.dw_w49 = (float*)dw_w49, bw.dw_b = (float*)dw_b, bw.ln_w = (float*)ln_w, bw.ln_b = (float*)ln_b;
+    bw.w1 = (float*)w1, bw.b1 = (float*)b1, bw.gamma = (float*)gamma, bw.beta = (float*)beta;
+    bw.w2 = (float*)w2, bw.b2 = (float*)b2;
+    const BlockWsSize z = block_ws_size(n, h, w, c);
+    BlockWs ws;
+    ws.t1 = ws_dev;
+    ws.t2 = ws.t1 + z.t;
+    ws.hid = ws.t2 + z.t;
+    ws.part = ws.hid + z.hid;
+    ws.scale = ws.part + z.part;
+    run_block(x_dev, out_dev, n, h, w, c, act, bw, ws, (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_op_l2norm(const float* x_dev, float* out_dev, int64_t rows, int32_t d, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(x_dev && out_dev, ERR_INVALID, "null argument");
+    l2norm_rows_launch(x_dev, out_dev, rows, d, (hipStream_t)stream);
+  });
+}
+
+}  // extern "C"

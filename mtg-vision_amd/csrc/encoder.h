@@ -1,0 +1,100 @@
+// ConvNeXt-V2 encoder executor: builds the layer plan from a config, owns weights and
+// workspace, runs the whole forward on one stream with hand-written kernels only.
+#pragma once
+#include "common.h"
+#include "gemm_f32.h"
+#include "mtgv.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace mtgv {
+
+struct DevBuf {
+  float* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void alloc(size_t floats);
+  void ensure(size_t floats) {
+    if (floats > n) alloc(floats);
+  }
+  void release();
+};
+
+// weights of one Block (convnextv2.py:198-207), device pointers
+struct BlockW {
+  float *dw_w49 = nullptr, *dw_b = nullptr, *ln_w = nullptr, *ln_b = nullptr;
+  float *w1 = nullptr, *b1 = nullptr, *gamma = nullptr, *beta = nullptr, *w2 = nullptr, *b2 = nullptr;
+};
+struct BlockWs {
+  float *t1 = nullptr, *t2 = nullptr, *hid = nullptr, *part = nullptr, *scale = nullptr;
+};
+struct BlockWsSize {
+  size_t t, hid, part, scale;
+  size_t total() const { return 2 * t + hid + part + scale; }
+};
+BlockWsSize block_ws_size(int n, int h, int w, int c);
+// Block.forward on NHWC x -> out (may not alias x)
+void run_block(const float* x, float* out, int n, int h, int w, int c, int act, const BlockW& bw, const BlockWs& ws,
+               hipStream_t s);
+
+GemmArgs linear_args(const float* A, int lda, const float* W, const float* bias, float* Out, int ldo, int M, int N, int K,
+                     int act);
+
+enum Repack { R_NONE = 0, R_OIHW_OHWI = 1, R_DW49 = 2, R_HEADPERM = 3 };
+
+struct ParamSlot {
+  std::vector<int> shape;  // reference shape
+  Repack repack = R_NONE;
+  int perm_p = 0, perm_c = 0;  // R_HEADPERM: input index (c*P + p) -> (p*zc + c)
+  float* dev = nullptr;
+  int64_t numel = 0;
+  bool set = false;
+};
+
+class ParamStore {
+ public:
+  ~ParamStore();
+  float* add(const std::string& key, std::vector<int> shape, Repack r = R_NONE, int perm_p = 0, int perm_c = 0);
+  void set(const std::string& key, const float* host, int64_t numel);
+  int missing() const;
+  const std::map<std::string, ParamSlot>& slots() const { return slots_; }
+
+ private:
+  std::map<std::string, ParamSlot> slots_;
+};
+
+class Encoder {
+ public:
+  explicit Encoder(const mtgv_encoder_cfg& cfg);
+  void set_param(const char* key, const float* host, int64_t numel) { params_.set(key, host, numel); }
+  int missing() const { return params_.missing(); }
+  void forward(const void* x, int layout, int n, float* z, hipStream_t s);
+  void set_capture(bool on);
+  void stage_output(int stage, int n, float* out, hipStream_t s);
+  void flops(double* gemm, double* dw) const;
+  const mtgv_encoder_cfg& cfg() const { return cfg_; }
+
+ private:
+  mtgv_encoder_cfg cfg_;
+  int act_;
+  int sh_[4], sw_[4];  // stage spatial sizes
+  ParamStore params_;
+  // weights
+  float *stem_w_, *stem_b_, *stem_ln_w_, *stem_ln_b_;
+  float *ds_ln_w_[4], *ds_ln_b_[4], *ds_w_[4], *ds_b_[4];
+  std::vector<BlockW> blocks_[4];
+  float *pool_w_ = nullptr, *pool_b_ = nullptr, *pool_ln_w_ = nullptr, *pool_ln_b_ = nullptr;
+  float *head_w_ = nullptr, *head_b_ = nullptr, *head2_w_ = nullptr, *head2_b_ = nullptr;
+  // workspace
+  DevBuf x0_, xa_, xb_, ws_, head_a_, head_b2_;
+  DevBuf stage_[4];
+  bool capture_ = false;
+  int last_n_ = 0;
+};
+
+}  // namespace mtgv

@@ -1,0 +1,422 @@
+// ConvNeXt-V2 encoder forward, NHWC end to end (the reference permutes NCHW<->NHWC twice
+// per block, convnextv2.py:215/:221; here the layout never changes).
+//
+// Per Block (convnextv2.py:212-224):
+//   dwconv7 (+bias)            -> t1            rowops.hip  dwconv7_kernel
+//   LayerNorm over C           -> t2            rowops.hip  ln_rows_kernel
+//   pwconv1 + bias + act, GRN sum(x^2) partials -> hid   gemm_f32 (epilogue)
+//   GRN finalize               -> scale[n][4C]  grn_finalize_kernel
+//   (hid*scale + beta) @ W2^T + b2 + residual -> out      gemm_f32 (A prologue + epilogue)
+#include "encoder.h"
+#include "rowops.h"
+
+#include <string.h>
+
+namespace mtgv {
+
+void DevBuf::alloc(size_t floats) {
+  release();
+  if (floats == 0) return;
+  HIP_OK(hipMalloc((void**)&p, floats * sizeof(float)));
+  n = floats;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  n = 0;
+}
+
+// ---------------------------------------------------------------------------
+// parameter store
+// ---------------------------------------------------------------------------
+ParamStore::~ParamStore() {
+  for (auto& kv : slots_)
+    if (kv.second.dev) (void)hipFree(kv.second.dev);
+}
+
+float* ParamStore::add(const std::string& key, std::vector<int> shape, Repack r, int perm_p, int perm_c) {
+  ParamSlot sl;
+  sl.shape = shape;
+  sl.repack = r;
+  sl.perm_p = perm_p;
+  sl.perm_c = perm_c;
+  sl.numel = 1;
+  for (int d : shape) sl.numel *= d;
+  HIP_OK(hipMalloc((void**)&sl.dev, (size_t)sl.numel * sizeof(float)));
+  MTGV_CHECK(slots_.find(key) == slots_.end(), ERR_INVALID, "duplicate parameter %s", key.c_str());
+  slots_[key] = sl;
+  return sl.dev;
+}
+
+void ParamStore::set(const std::string& key, const float* host, int64_t numel) {
+  auto it = slots_.find(key);
+  MTGV_CHECK(it != slots_.end(), ERR_KEY, "unknown parameter key '%s'", key.c_str());
+  ParamSlot& sl = it->second;
+  MTGV_CHECK(numel == sl.numel, ERR_INVALID, "parameter %s: got %lld elements, expected %lld", key.c_str(), (long long)numel,
+             (long long)sl.numel);
+  std::vector<float> tmp;
+  const float* src = host;
+  if (sl.repack == R_OIHW_OHWI) {
+    const int O = sl.shape[0], I = sl.shape[1], KH = sl.shape[2], KW = sl.shape[3];
+    tmp.resize((size_t)numel);
+    for (int o = 0; o < O; ++o)
+      for (int i = 0; i < I; ++i)
+        for (int kh = 0; kh < KH; ++kh)
+          for (int kw = 0; kw < KW; ++kw)
+            tmp[(((size_t)o * KH + kh) * KW + kw) * I + i] = host[(((size_t)o * I + i) * KH + kh) * KW + kw];
+    src = tmp.data();
+  } else if (sl.repack == R_DW49) {
+    const int C = sl.shape[0];
+    tmp.resize((size_t)numel);
+    for (int c = 0; c < C; ++c)
+      for (int t = 0; t < 49; ++t) tmp[(size_t)t * C + c] = host[(size_t)c * 49 + t];
+    src = tmp.data();
+  } else if (sl.repack == R_HEADPERM) {
+    // columns arrive in NCHW-flat order (c*P + p) (Reshape((-1, z)), convnextv2ae.py:230);
+    // activations here are NHWC-flat (p*zc + c)
+    const int Z = sl.shape[0], IN = sl.shape[1], P = sl.perm_p, ZC = sl.perm_c;
+    MTGV_CHECK(P * ZC == IN, ERR_INVALID, "head permutation mismatch");
+    tmp.resize((size_t)numel);
+    for (int o = 0; o < Z; ++o)
+      for (int c = 0; c < ZC; ++c)
+        for (int p = 0; p < P; ++p) tmp[(size_t)o * IN + (size_t)p * ZC + c] = host[(size_t)o * IN + (size_t)c * P + p];
+    src = tmp.data();
+  }
+  HIP_OK(hipMemcpy(sl.dev, src, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
+  sl.set = true;
+}
+
+int ParamStore::missing() const {
+  int m = 0;
+  for (auto& kv : slots_) m += kv.second.set ? 0 : 1;
+  return m;
+}
+
+// ---------------------------------------------------------------------------
+// one block
+// ---------------------------------------------------------------------------
+GemmArgs linear_args(const float* A, int lda, const float* W, const float* bias, float* Out, int ldo, int M, int N, int K,
+                     int act) {
+  GemmArgs a;
+  a.A = A;
+  a.W = W;
+  a.Out = Out;
+  a.bias = bias;
+  a.M = M, a.N = N, a.K = K;
+  a.c_total = lda;
+  a.Cin = K;
+  a.ldo = ldo;
+  a.act = act;
+  return a;
+}
+
+BlockWsSize block_ws_size(int n, int h, int w, int c) {
+  BlockWsSize z;
+  const size_t M = (size_t)n * h * w;
+  z.t = M * c;
+  z.hid = M * 4 * c;
+  const GemmPlan pl = gemm_plan((int)M, 4 * c, c);
+  z.part = gemm_grn_part_floats(pl, 4 * c, h * w);
+  z.scale = (size_t)n * 4 * c;
+  return z;
+}
+
+void run_block(const float* x, float* out, int n, int h, int w, int c, int act, const BlockW& bw, const BlockWs& ws,
+               hipStream_t s) {
+  const int M = n * h * w, hw = h * w;
+  dwconv7_launch(x, bw.dw_w49, bw.dw_b, ws.t1, n, h, w, c, s);
+  ln_rows_launch(ws.t1, c, 0, ws.t2, c, 0, bw.ln_w, bw.ln_b, M, c, 1e-6f, s);
+
+  GemmArgs g1 = linear_args(ws.t2, c, bw.w1, bw.b1, ws.hid, 4 * c, M, 4 * c, c, act);
+  const GemmPlan p1 = gemm_plan(M, 4 * c, c);
+  g1.grn_part = ws.part;
+  g1.hw = hw;
+  g1.segmax = gemm_grn_segmax(p1, hw);
+  gemm_launch(g1, p1, s);
+
+  grn_finalize_launch(ws.part, p1, n, hw, 4 * c, bw.gamma, ws.scale, s);
+
+  GemmArgs g2 = linear_args(ws.hid, 4 * c, bw.w2, bw.b2, out, c, M, c, 4 * c, ACT_NONE);
+  g2.res = x;
+  g2.ldr = c;
+  g2.hw = hw;
+  g2.a_scale = ws.scale;
+  g2.a_shift = bw.beta;
+  gemm_launch(g2, gemm_plan(M, c, 4 * c), s);
+}
+
+// ---------------------------------------------------------------------------
+// Encoder
+// ---------------------------------------------------------------------------
+static std::string blk_key(int kind, int s, int j, const char* leaf) {
+  char b[128];
+  if (kind == MTGV_ENC_AE)
+    snprintf(b, sizeof(b), "block%d.2.%d.%s", s, j, leaf);
+  else
+    snprintf(b, sizeof(b), "stages.%d.%d.%s", s, j, leaf);
+  return b;
+}
+
+Encoder::Encoder(const mtgv_encoder_cfg& cfg) : cfg_(cfg) {
+  MTGV_CHECK(cfg.kind == MTGV_ENC_AE || cfg.kind == MTGV_ENC_PLAIN, ERR_KEY, "encoder kind=%d not recognized", cfg.kind);
+  MTGV_CHECK(cfg.in_chans == 3, ERR_INVALID, "in_chans=%d (only 3 supported)", cfg.in_chans);
+  MTGV_CHECK(cfg.image_h > 0 && cfg.image_w > 0 && cfg.image_h % 32 == 0 && cfg.image_w % 32 == 0, ERR_INVALID,
+             "image %dx%d must be a positive multiple of 32 (convnextv2ae.py:137-139)", cfg.image_h, cfg.image_w);
+  MTGV_CHECK(cfg.max_batch > 0, ERR_INVALID, "max_batch=%d", cfg.max_batch);
+  for (int i = 0; i < 4; ++i)
+    MTGV_CHECK(cfg.depths[i] > 0 && cfg.dims[i] > 0 && cfg.dims[i] % 4 == 0, ERR_INVALID, "stage %d: depth=%d dim=%d", i,
+               cfg.depths[i], cfg.dims[i]);
+  const int P = (cfg.image_h / 32) * (cfg.image_w / 32);
+  const int ht = cfg.head_type;
+  if (cfg.kind == MTGV_ENC_AE) {
+    MTGV_CHECK(ht >= MTGV_HEAD_CONV_LINEAR && ht <= MTGV_HEAD_POOL_MLP, ERR_KEY, "head_type=%d not recognized", ht);
+    MTGV_CHECK(cfg.z_size % P == 0, ERR_INVALID, "z_size=%d %% internal_num=%d != 0 (convnextv2ae.py:126)", cfg.z_size, P);
+  } else {
+    MTGV_CHECK(ht == MTGV_HEAD_PLAIN, ERR_KEY, "plain encoder needs head_type plain");
+  }
+  MTGV_CHECK(cfg.z_size % 4 == 0, ERR_INVALID, "z_size=%d must be a multiple of 4", cfg.z_size);
+  act_ = cfg.kind == MTGV_ENC_AE ? ACT_MISH : ACT_GELU;
+  for (int s = 0; s < 4; ++s) {
+    sh_[s] = cfg.image_h / (4 << s);
+    sw_[s] = cfg.image_w / (4 << s);
+  }
+  const bool ae = cfg.kind == MTGV_ENC_AE;
+  const int* d = cfg.dims;
+  char k[128];
+
+  // stem: Conv2d(3, C0, k4, s4) + LN  (convnextv2ae.py:193-196 / convnextv2.py:253-256)
+  const char* stem_conv = ae ? "block0.0" : "downsample_layers.0.0";
+  const char* stem_ln = ae ? "block0.1" : "downsample_layers.0.1";
+  snprintf(k, sizeof(k), "%s.weight", stem_conv);
+  stem_w_ = params_.add(k, {d[0], 3, 4, 4}, R_OIHW_OHWI);
+  snprintf(k, sizeof(k), "%s.bias", stem_conv);
+  stem_b_ = params_.add(k, {d[0]});
+  snprintf(k, sizeof(k), "%s.weight", stem_ln);
+  stem_ln_w_ = params_.add(k, {d[0]});
+  snprintf(k, sizeof(k), "%s.bias", stem_ln);
+  stem_ln_b_ = params_.add(k, {d[0]});
+  for (int s = 1; s < 4; ++s) {
+    char ln[64], cv[64];
+    if (ae) {
+      snprintf(ln, sizeof(ln), "block%d.0", s);
+      snprintf(cv, sizeof(cv), "block%d.1", s);
+    } else {
+      snprintf(ln, sizeof(ln), "downsample_layers.%d.0", s);
+      snprintf(cv, sizeof(cv), "downsample_layers.%d.1", s);
+    }
+    ds_ln_w_[s] = params_.add(std::string(ln) + ".weight", {d[s - 1]});
+    ds_ln_b_[s] = params_.add(std::string(ln) + ".bias", {d[s - 1]});
+    ds_w_[s] = params_.add(std::string(cv) + ".weight", {d[s], d[s - 1], 2, 2}, R_OIHW_OHWI);
+    ds_b_[s] = params_.add(std::string(cv) + ".bias", {d[s]});
+  }
+  for (int s = 0; s < 4; ++s) {
+    const int c = d[s];
+    for (int j = 0; j < cfg.depths[s]; ++j) {
+      BlockW b;
+      b.dw_w49 = params_.add(blk_key(cfg.kind, s, j, "dwconv.weight"), {c, 1, 7, 7}, R_DW49);
+      b.dw_b = params_.add(blk_key(cfg.kind, s, j, "dwconv.bias"), {c});
+      b.ln_w = params_.add(blk_key(cfg.kind, s, j, "norm.weight"), {c});
+      b.ln_b = params_.add(blk_key(cfg.kind, s, j, "norm.bias"), {c});
+      b.w1 = params_.add(blk_key(cfg.kind, s, j, "pwconv1.weight"), {4 * c, c});
+      b.b1 = params_.add(blk_key(cfg.kind, s, j, "pwconv1.bias"), {4 * c});
+      b.gamma = params_.add(blk_key(cfg.kind, s, j, "grn.gamma"), {1, 1, 1, 4 * c});
+      b.beta = params_.add(blk_key(cfg.kind, s, j, "grn.beta"), {1, 1, 1, 4 * c});
+      b.w2 = params_.add(blk_key(cfg.kind, s, j, "pwconv2.weight"), {c, 4 * c});
+      b.b2 = params_.add(blk_key(cfg.kind, s, j, "pwconv2.bias"), {c});
+      blocks_[s].push_back(b);
+    }
+  }
+  const int z = cfg.z_size, c3 = d[3];
+  if (ht == MTGV_HEAD_PLAIN) {
+    pool_ln_w_ = params_.add("norm.weight", {c3});
+    pool_ln_b_ = params_.add("norm.bias", {c3});
+    head_w_ = params_.add("head.weight", {z, c3});
+    head_b_ = params_.add("head.bias", {z});
+  } else {
+    const bool conv_head = ht <= MTGV_HEAD_CONV_ACT_MLP;
+    const bool mlp = ht == MTGV_HEAD_CONV_MLP || ht == MTGV_HEAD_CONV_ACT_MLP || ht == MTGV_HEAD_POOL_MLP;
+    int head_in;
+    if (conv_head) {
+      const int zc = z / P;
+      pool_w_ = params_.add("pool.0.weight", {zc, c3, 1, 1});
+      pool_b_ = params_.add("pool.0.bias", {zc});
+      pool_ln_w_ = params_.add("pool.2.weight", {zc});
+      pool_ln_b_ = params_.add("pool.2.bias", {zc});
+      head_in = z;
+      if (mlp) {
+        head_w_ = params_.add("head.layers.0.weight", {z, head_in}, R_HEADPERM, P, zc);
+        head_b_ = params_.add("head.layers.0.bias", {z});
+      } else {
+        head_w_ = params_.add("head.weight", {z, head_in}, R_HEADPERM, P, zc);
+        head_b_ = params_.add("head.bias", {z});
+      }
+    } else {
+      pool_ln_w_ = params_.add("pool.1.weight", {c3});
+      pool_ln_b_ = params_.add("pool.1.bias", {c3});
+      head_in = c3;
+      if (mlp) {
+        head_w_ = params_.add("head.layers.0.weight", {z, head_in});
+        head_b_ = params_.add("head.layers.0.bias", {z});
+      } else {
+        head_w_ = params_.add("head.weight", {z, head_in});
+        head_b_ = params_.add("head.bias", {z});
+      }
+    }
+    if (mlp) {
+      head2_w_ = params_.add("head.layers.2.weight", {z, z});
+      head2_b_ = params_.add("head.layers.2.bias", {z});
+    }
+  }
+
+  // workspace for max_batch
+  const int nb = cfg.max_batch;
+  x0_.alloc((size_t)nb * cfg.image_h * cfg.image_w * 3);
+  size_t act_max = 0, ws_max = 0;
+  for (int s = 0; s < 4; ++s) {
+    act_max = std::max(act_max, (size_t)nb * sh_[s] * sw_[s] * d[s]);
+    ws_max = std::max(ws_max, block_ws_size(nb, sh_[s], sw_[s], d[s]).total());
+  }
+  xa_.alloc(act_max);
+  xb_.alloc(act_max);
+  ws_.alloc(ws_max);
+  head_a_.alloc((size_t)nb * std::max(z, c3) + 16);
+  head_b2_.alloc((size_t)nb * std::max(z, c3) + 16);
+}
+
+void Encoder::set_capture(bool on) {
+  capture_ = on;
+  if (on)
+    for (int s = 0; s < 4; ++s) stage_[s].ensure((size_t)cfg_.max_batch * sh_[s] * sw_[s] * cfg_.dims[s]);
+}
+
+void Encoder::stage_output(int stage, int n, float* out, hipStream_t s) {
+  MTGV_CHECK(capture_, ERR_RUNTIME, "stage capture is not enabled");
+  MTGV_CHECK(stage >= 0 && stage < 4 && n > 0 && n <= last_n_, ERR_INVALID, "stage=%d n=%d", stage, n);
+  HIP_OK(hipMemcpyAsync(out, stage_[stage].p, (size_t)n * sh_[stage] * sw_[stage] * cfg_.dims[stage] * sizeof(float),
+                        hipMemcpyDeviceToDevice, s));
+}
+
+void Encoder::flops(double* gemm, double* dw) const {
+  double g = 0, w = 0;
+  const int* d = cfg_.dims;
+  g += 2.0 * sh_[0] * sw_[0] * d[0] * 48;
+  for (int s = 1; s < 4; ++s) g += 2.0 * sh_[s] * sw_[s] * d[s] * 4 * d[s - 1];
+  for (int s = 0; s < 4; ++s) {
+    const double hw = (double)sh_[s] * sw_[s];
+    g += cfg_.depths[s] * 2.0 * (2.0 * hw * d[s] * 4 * d[s]);
+    w += cfg_.depths[s] * 2.0 * 49 * hw * d[s];
+  }
+  const int z = cfg_.z_size, c3 = d[3], P = sh_[3] * sw_[3];
+  const int ht = cfg_.head_type;
+  const bool mlp = ht == MTGV_HEAD_CONV_MLP || ht == MTGV_HEAD_CONV_ACT_MLP || ht == MTGV_HEAD_POOL_MLP;
+  if (ht <= MTGV_HEAD_CONV_ACT_MLP) {
+    g += 2.0 * P * (z / P) * c3 + 2.0 * z * z;
+  } else {
+    g += 2.0 * z * c3;
+  }
+  if (mlp) g += 2.0 * z * z;
+  if (gemm) *gemm = g;
+  if (dw) *dw = w;
+}
+
+void Encoder::forward(const void* x, int layout, int n, float* z_out, hipStream_t s) {
+  MTGV_CHECK(params_.missing() == 0, ERR_RUNTIME, "encoder has %d unset parameters", params_.missing());
+  MTGV_CHECK(n > 0 && n <= cfg_.max_batch, ERR_INVALID, "batch %d outside [1, %d]", n, cfg_.max_batch);
+  MTGV_CHECK(x != nullptr && z_out != nullptr, ERR_INVALID, "null tensor");
+  const int H = cfg_.image_h, W = cfg_.image_w;
+  const float sc = cfg_.scale_io ? 2.0f : 1.0f, sf = cfg_.scale_io ? -1.0f : 0.0f;
+  if (layout == MTGV_IN_NCHW_F32)
+    nchw_to_nhwc_launch((const float*)x, x0_.p, n, 3, H, W, 3, sc, sf, s);
+  else if (layout == MTGV_IN_NHWC_F32)
+    f32hwc_scale_launch((const float*)x, x0_.p, (long)n * H * W, 3, 3, sc, sf, s);
+  else if (layout == MTGV_IN_NHWC_U8)
+    u8_to_f32_launch((const uint8_t*)x, x0_.p, (long)n * H * W, 3, 3, sc, sf, 0, s);
+  else
+    MTGV_CHECK(false, ERR_INVALID, "unknown input layout %d", layout);
+
+  const int* d = cfg_.dims;
+  float* cur = xa_.p;
+  float* alt = xb_.p;
+
+  // stem: rows of 12 floats (4 pixels x RGB) are the "pixels" of a (4 x 1) conv, stride (4, 1)
+  {
+    GemmArgs g;
+    g.A = x0_.p;
+    g.W = stem_w_;
+    g.bias = stem_b_;
+    g.Out = alt;
+    g.M = n * sh_[0] * sw_[0], g.N = d[0], g.K = 48;
+    g.H = H, g.Wd = W / 4, g.c_total = 12, g.Cin = 12;
+    g.KH = 4, g.KW = 1, g.stride = 4, g.stride_w = 1, g.pad = 0;
+    g.OH = sh_[0], g.OW = sw_[0], g.OH2 = sh_[0], g.OW2 = sw_[0];
+    g.ldo = d[0];
+    gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+    ln_rows_launch(alt, d[0], 0, cur, d[0], 0, stem_ln_w_, stem_ln_b_, g.M, d[0], 1e-6f, s);
+  }
+
+  for (int st = 0; st < 4; ++st) {
+    const int h = sh_[st], w = sw_[st], c = d[st];
+    if (st > 0) {
+      // LayerNorm(channels_first) + Conv2d(k2, s2): convnextv2.py:258-263
+      const int hp = sh_[st - 1], wp = sw_[st - 1], cp = d[st - 1];
+      ln_rows_launch(cur, cp, 0, alt, cp, 0, ds_ln_w_[st], ds_ln_b_[st], (long)n * hp * wp, cp, 1e-6f, s);
+      GemmArgs g;
+      g.A = alt;
+      g.W = ds_w_[st];
+      g.bias = ds_b_[st];
+      g.Out = cur;
+      g.M = n * h * w, g.N = c, g.K = 4 * cp;
+      g.H = hp, g.Wd = wp, g.c_total = cp, g.Cin = cp;
+      g.KH = 2, g.KW = 2, g.stride = 2, g.pad = 0;
+      g.OH = h, g.OW = w, g.OH2 = h, g.OW2 = w;
+      g.ldo = c;
+      gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+    }
+    const BlockWsSize z = block_ws_size(n, h, w, c);
+    BlockWs ws;
+    ws.t1 = ws_.p;
+    ws.t2 = ws.t1 + z.t;
+    ws.hid = ws.t2 + z.t;
+    ws.part = ws.hid + z.hid;
+    ws.scale = ws.part + z.part;
+    for (size_t j = 0; j < blocks_[st].size(); ++j) {
+      run_block(cur, alt, n, h, w, c, act_, blocks_[st][j], ws, s);
+      std::swap(cur, alt);
+    }
+    if (capture_)
+      HIP_OK(hipMemcpyAsync(stage_[st].p, cur, (size_t)n * h * w * c * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+
+  // head
+  const int zs = cfg_.z_size, c3 = d[3], P = sh_[3] * sw_[3];
+  const int ht = cfg_.head_type;
+  const bool mlp = ht == MTGV_HEAD_CONV_MLP || ht == MTGV_HEAD_CONV_ACT_MLP || ht == MTGV_HEAD_POOL_MLP;
+  float* feat = head_a_.p;  // input rows of the head linear
+  int feat_dim;
+  if (ht <= MTGV_HEAD_CONV_ACT_MLP) {
+    // Conv1x1 C3 -> z/P [+Mish] -> LN over channels -> NHWC-flat (n, P*zc); convnextv2ae.py:219-231
+    const int zc = zs / P;
+    GemmArgs g = linear_args(cur, c3, pool_w_, pool_b_, head_b2_.p, zc, n * P, zc, c3,
+                             ht == MTGV_HEAD_CONV_ACT_MLP ? ACT_MISH : ACT_NONE);
+    gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+    ln_rows_launch(head_b2_.p, zc, 0, feat, zc, 0, pool_ln_w_, pool_ln_b_, (long)n * P, zc, 1e-6f, s);
+    feat_dim = zs;
+  } else {
+    // GAP -> LN over C3: convnextv2ae.py:236-244 / convnextv2.py:292-296
+    gap_launch(cur, head_b2_.p, n, P, c3, s);
+    ln_rows_launch(head_b2_.p, c3, 0, feat, c3, 0, pool_ln_w_, pool_ln_b_, n, c3, 1e-6f, s);
+    feat_dim = c3;
+  }
+  if (mlp) {
+    GemmArgs g = linear_args(feat, feat_dim, head_w_, head_b_, head_b2_.p, zs, n, zs, feat_dim, ACT_MISH);
+    gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+    GemmArgs g2 = linear_args(head_b2_.p, zs, head2_w_, head2_b_, z_out, zs, n, zs, zs, ACT_NONE);
+    gemm_launch(g2, gemm_plan(g2.M, g2.N, g2.K), s);
+  } else {
+    GemmArgs g = linear_args(feat, feat_dim, head_w_, head_b_, z_out, zs, n, zs, feat_dim, ACT_NONE);
+    gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+  }
+  last_n_ = n;
+}
+
+}  // namespace mtgv

@@ -1,0 +1,70 @@
+// Implicit-GEMM convolution / linear layer on the gfx950 f32 matrix cores.
+//
+//   Out[orow(m)][o_off + n] = act( sum_k A(m,k) * W[n][k] + bias[n] ) (+ res[m][n])
+//
+// A(m,k) is gathered on the fly from an NHWC activation tensor (no im2col):
+//   m -> (img, oh, ow), k -> (kh, kw, c), A = in[img][oh*s+kh-p][ow*s+kw-p][c_off+c].
+// W is [N][K] row-major with K ordered (kh, kw, c) - the same order nn.Linear
+// uses for 1x1 (convnextv2.py:202-207) and what conv weights are repacked to
+// at load time.
+#pragma once
+#include "common.h"
+
+namespace mtgv {
+
+struct GemmArgs {
+  const float* A = nullptr;     // NHWC activation base
+  const float* W = nullptr;     // [N][K]
+  float* Out = nullptr;
+  const float* bias = nullptr;  // [N] or null
+  const float* res = nullptr;   // residual [M][ldr] or null
+  int M = 0, N = 0, K = 0;
+
+  // A gather geometry (1x1/linear: KH=KW=1, stride=1, pad=0, H*W = rows per image)
+  int H = 1, Wd = 1;            // input spatial size
+  int c_total = 0;              // input channel stride (floats per pixel)
+  int c_off = 0;                // first input channel used
+  int Cin = 0;                  // channels consumed per tap (K = KH*KW*Cin)
+  int KH = 1, KW = 1, stride = 1, pad = 0;
+  int stride_w = 0;             // 0 = same as stride (the 4x4 stem views rows of 12 floats as pixels: stride 4 x 1)
+  int OH = 1, OW = 1;           // output grid that m enumerates
+
+  // output mapping: orow = (img*OH2 + oh*os + oy)*OW2 + ow*os + ox
+  int ldo = 0, o_off = 0;
+  int os = 1, oy = 0, ox = 0, OH2 = 1, OW2 = 1;
+  int ldr = 0;
+  int act = ACT_NONE;
+
+  // GRN (convnextv2.py:171-174): per-(tile, image-segment, n) partial sums of out^2
+  float* grn_part = nullptr;    // [tiles_m][segmax][N]
+  int hw = 0;                   // rows per image for GRN / prologue segmentation
+  int segmax = 0;
+  // GRN apply fused into the A load of pwconv2: a' = a * a_scale[img][k] + a_shift[k]
+  const float* a_scale = nullptr;
+  const float* a_shift = nullptr;
+
+  // match path: instead of storing Out, keep the top-`topk` (score desc, id asc)
+  // columns of every row per column tile: cand[m][tile_n][topk]
+  float* cand_s = nullptr;
+  int* cand_i = nullptr;
+  int topk = 0;
+};
+
+struct GemmPlan {
+  int tm, tn, bk;               // tile: BM = 128*tm, BN = 32*tn
+  int tiles_m, tiles_n;
+  int bm() const { return 128 * tm; }
+  int bn() const { return 32 * tn; }
+};
+
+GemmPlan gemm_plan(int M, int N, int K);
+int gemm_grn_segmax(const GemmPlan& p, int hw);
+size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw);
+void gemm_launch(const GemmArgs& a, const GemmPlan& p, hipStream_t s);
+
+// sum the partials of one GEMM into the GRN apply table
+//   scale[img][n] = gamma[n] * Gx / (mean_n Gx + 1e-6) + 1,  Gx = sqrt(sum x^2)
+void grn_finalize_launch(const float* part, const GemmPlan& p, int n_img, int hw, int N, const float* gamma,
+                         float* scale, hipStream_t s);
+
+}  // namespace mtgv

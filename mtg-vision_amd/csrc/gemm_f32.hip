@@ -1,0 +1,455 @@
+// Implicit-GEMM conv / linear on gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Why f32 MFMA: the path's contract is fp32 embeddings within 1e-4 of the
+// PyTorch CPU reference and identical top-1 ids; plain fp16 operands miss that
+// by 25x.  gfx950 has no TF32, but it does have an exact
+// f32-in/f32-acc matrix instruction (157 TFLOP/s dense), so every GEMM-shaped
+// op of the path runs on it.
+//
+// Tile: 256 threads = 4 waves stacked along M.  Block tile BM = 128*TM rows by
+// BN = 32*TN columns; wave w owns rows [w*32*TM, (w+1)*32*TM) x all BN columns
+// as TM x TN accumulators of 32x32.  K is consumed in BK-wide steps staged
+// through LDS (rows padded by 16 B so ds_read_b128 is conflict-free), with the
+// next step's global loads in flight while the current one feeds the MFMAs.
+#include "gemm_f32.h"
+#include "act.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace mtgv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmDev {
+  GemmArgs a;
+  FastDiv d_ohw, d_ow, d_cin, d_kwcin, d_hw;
+  int tiles_m, tiles_n;
+  int remap;  // output rows are not simply m
+};
+
+template <int TM, int TN, int BK, bool CONV, bool APRO, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
+  constexpr int BM = 128 * TM, BN = 32 * TN, LS = BK + 4;
+  constexpr int KQ = BK / 4;      // float4 per staged row
+  constexpr int RPP = 256 / KQ;   // rows staged per pass
+  constexpr int AP = BM / RPP;
+  constexpr int BP = (BN + RPP - 1) / RPP;
+  static_assert(BM % RPP == 0, "A tile must be a whole number of passes");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                // [2][BM][LS]
+  float* Bs = smem + 2 * BM * LS;  // [2][BN][LS]
+
+  const GemmArgs& p = g.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // XCD-aware tile order: blocks that share an XCD (equal blockIdx % 8) walk a
+  // contiguous run of tiles, n fastest, so an A row-panel is fetched once per L2.
+  int L;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  const int tile_n = L % g.tiles_n, tile_m = L / g.tiles_n;
+  const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+
+  // ---- loader state: each thread stages fixed rows, one float4 column ----
+  const int lrow = tid / KQ, lk = (tid % KQ) * 4;
+  long a_row[AP];   // CONV: pixel index of image start; dense: element offset of row
+  int a_ih0[AP], a_iw0[AP];
+  long a_srow[AP];  // APRO: element offset of the image's scale row
+  bool a_ok[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int m = bm0 + lrow + i * RPP;
+    a_ok[i] = m < p.M;
+    const uint32_t mm = a_ok[i] ? (uint32_t)m : 0u;
+    if (CONV) {
+      const uint32_t img = fdiv(mm, g.d_ohw);
+      const uint32_t rem = mm - img * (uint32_t)(p.OH * p.OW);
+      const uint32_t oh = fdiv(rem, g.d_ow);
+      const uint32_t ow = rem - oh * (uint32_t)p.OW;
+      a_row[i] = (long)img * p.H * p.Wd;
+      a_ih0[i] = (int)oh * p.stride - p.pad;
+      a_iw0[i] = (int)ow * (p.stride_w > 0 ? p.stride_w : p.stride) - p.pad;
+    } else {
+      a_row[i] = (long)mm * p.c_total + p.c_off;
+      a_ih0[i] = a_iw0[i] = 0;
+    }
+    a_srow[i] = APRO ? (long)fdiv(mm, g.d_hw) * p.K : 0;
+  }
+  long b_row[BP];
+  bool b_ok[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int rr = lrow + i * RPP;
+    const int n = bn0 + rr;
+    b_ok[i] = (rr < BN) && (n < p.N);
+    b_row[i] = (long)(b_ok[i] ? n : 0) * p.K;
+  }
+
+  f32x4 ra[AP], rb[BP];
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK + lk;
+    const bool kok = k < p.K;
+    int kh = 0, kw = 0, c = 0;
+    if (CONV) {
+      const uint32_t kk = kok ? (uint32_t)k : 0u;
+      kh = (int)fdiv(kk, g.d_kwcin);
+      const uint32_t r = kk - (uint32_t)kh * (uint32_t)(p.KW * p.Cin);
+      kw = (int)fdiv(r, g.d_cin);
+      c = (int)(r - (uint32_t)kw * (uint32_t)p.Cin);
+    }
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (CONV) {
+        const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+        if (a_ok[i] && kok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.Wd)
+          v = *reinterpret_cast<const f32x4*>(p.A + (a_row[i] + (long)ih * p.Wd + iw) * p.c_total + p.c_off + c);
+      } else {
+        if (a_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(p.A + a_row[i] + k);
+      }
+      if (APRO) {
+        if (a_ok[i] && kok) {
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.a_scale + a_srow[i] + k);
+          const f32x4 h4 = *reinterpret_cast<const f32x4*>(p.a_shift + k);
+          v = v * s4 + h4;
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(p.W + b_row[i] + k);
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i)
+      *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + i * RPP) * LS + lk]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BP; ++i)
+      if (lrow + i * RPP < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + i * RPP) * LS + lk]) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int col = lane & 31, half = lane >> 5;
+  const int arow = wave * 32 * TM + col;
+  const int kh4 = 4 * half;
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* Ab = As + cur * BM * LS;
+    const float* Bb = Bs + cur * BN * LS;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      // lane half h holds k = kk*8 + 4h + j in element j; A and B use the same
+      // k assignment, so MFMA j multiplies matching k pairs {j, 4+j}.
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&Ab[(arow + i * 32) * LS + kk * 8 + kh4]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bb[(j * 32 + col) * LS + kk * 8 + kh4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  if constexpr (EPI == 1) {
+    // ---- fused per-tile top-k (match path): the tile's scores never leave registers.
+    // A row's BN scores sit in the 32 lanes of one wave half x TN registers; each
+    // round picks the (score desc, id asc) maximum with a 5-step butterfly and
+    // retires it.  Candidates go to cand[m][tile_n][kk]; a merge kernel finishes.
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bool nok = (bn0 + j * 32 + col) < p.N;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!nok) acc[i][j][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm0 + wave * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        for (int kk = 0; kk < p.topk; ++kk) {
+          float bs = -INFINITY;
+          int bi = 0x7fffffff;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float v = acc[i][j][r];
+            if (v > bs) bs = v, bi = bn0 + j * 32 + col;
+          }
+#pragma unroll
+          for (int mask = 16; mask > 0; mask >>= 1) {
+            const float os = __shfl_xor(bs, mask);
+            const int oi = __shfl_xor(bi, mask);
+            if (os > bs || (os == bs && oi < bi)) bs = os, bi = oi;
+          }
+          if (col == 0 && m < p.M) {
+            const long o = ((long)m * g.tiles_n + tile_n) * p.topk + kk;
+            p.cand_s[o] = bs;
+            p.cand_i[o] = (bs == -INFINITY) ? -1 : bi;
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (bn0 + j * 32 + col == bi) acc[i][j][r] = -INFINITY;
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue: bias, activation, residual, store (C layout: col = lane&31,
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = bn0 + j * 32 + col;
+    const bool nok = n < p.N;
+    const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm0 + wave * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = 0.f;
+        if (m < p.M && nok) {
+          v = apply_act(acc[i][j][r] + bv, p.act);
+          float o = v;
+          if (p.res != nullptr) o += p.res[(long)m * p.ldr + n];
+          long orow = m;
+          if (g.remap) {
+            const uint32_t img = fdiv((uint32_t)m, g.d_ohw);
+            const uint32_t rem = (uint32_t)m - img * (uint32_t)(p.OH * p.OW);
+            const uint32_t oh = fdiv(rem, g.d_ow);
+            const uint32_t ow = rem - oh * (uint32_t)p.OW;
+            orow = ((long)img * p.OH2 + oh * p.os + p.oy) * p.OW2 + ow * p.os + p.ox;
+          }
+          p.Out[orow * p.ldo + p.o_off + n] = o;
+        }
+        acc[i][j][r] = v;
+      }
+    }
+  }
+
+  // ---- GRN partial sums of squares, segmented by image, fixed summation order ----
+  if (p.grn_part != nullptr) {
+    float* red = smem;  // [4][BN]; the K loop ended on a barrier, LDS is free
+    const int m_end = (bm0 + BM < p.M) ? bm0 + BM : p.M;
+    const int img_first = (int)fdiv((uint32_t)bm0, g.d_hw);
+    const int img_last = (int)fdiv((uint32_t)(m_end - 1), g.d_hw);
+    for (int s = 0; s <= img_last - img_first; ++s) {
+      const int lo = (img_first + s) * p.hw, hi = lo + p.hw;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = bm0 + wave * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float v = acc[i][j][r];
+            sum += (m >= lo && m < hi) ? v * v : 0.f;
+          }
+        sum += __shfl_xor(sum, 32);
+        if (half == 0) red[wave * BN + j * 32 + col] = sum;
+      }
+      __syncthreads();
+      if (tid < BN) {
+        const int n = bn0 + tid;
+        if (n < p.N)
+          p.grn_part[((long)tile_m * p.segmax + s) * p.N + n] =
+              ((red[tid] + red[BN + tid]) + red[2 * BN + tid]) + red[3 * BN + tid];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+GemmPlan gemm_plan(int M, int N, int K) {
+  GemmPlan pl;
+  if (const char* e = getenv("MTGV_GEMM_TILE")) {
+    int tm = 0, tn = 0, bk = 0;
+    if (sscanf(e, "%d,%d,%d", &tm, &tn, &bk) == 3 && (tm == 1 || (tm == 2 && tn == 2)) && tn >= 1 && tn <= 5 &&
+        (bk == 16 || bk == 32)) {
+      pl.tm = tm, pl.tn = tn, pl.bk = bk;
+      pl.tiles_m = ceil_div(M, pl.bm());
+      pl.tiles_n = ceil_div(N, pl.bn());
+      return pl;
+    }
+  }
+  // widest column tile with the least padding (ties -> wider)
+  int best_tn = 1;
+  long best_pad = -1;
+  for (int tn = 1; tn <= 5; ++tn) {
+    const long padded = (long)ceil_div(N, 32 * tn) * 32 * tn;
+    // a 160-wide tile only when it divides N exactly (it costs occupancy)
+    if (tn == 5 && padded != N) continue;
+    if (best_pad < 0 || padded < best_pad || (padded == best_pad && tn >= best_tn)) best_pad = padded, best_tn = tn;
+  }
+  pl.tm = 1;
+  pl.tn = best_tn;
+  const int rem = K % 32;
+  pl.bk = (pl.tn >= 5 || (rem > 0 && rem <= 16)) ? 16 : 32;
+  pl.tiles_m = ceil_div(M, pl.bm());
+  pl.tiles_n = ceil_div(N, pl.bn());
+  return pl;
+}
+
+int gemm_grn_segmax(const GemmPlan& p, int hw) { return (p.bm() - 1) / hw + 2; }
+
+size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw) {
+  return (size_t)p.tiles_m * gemm_grn_segmax(p, hw) * N;
+}
+
+template <int TM, int TN, int BK>
+static void launch_variant(const GemmDev& g, bool conv, bool apro, int grid, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * (128 * TM + 32 * TN) * (BK + 4) * sizeof(float);
+  static bool attr_done = false;  // >64 KiB of dynamic LDS must be opted into once per kernel
+  if (!attr_done) {
+    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<TM, TN, BK, false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<TM, TN, BK, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<TM, TN, BK, false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  if (apro) {
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, false, true, 0>), dim3(grid), dim3(256), lds, s, g);
+  } else if (conv) {
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, true, false, 0>), dim3(grid), dim3(256), lds, s, g);
+  } else {
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, false, false, 0>), dim3(grid), dim3(256), lds, s, g);
+  }
+}
+
+// match path: scores + per-tile top-k, one tile shape (128 queries x 128 bank rows, BK 32)
+static void launch_topk(const GemmDev& g, int grid, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * (128 + 128) * (32 + 4) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<1, 4, 32, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 32, false, false, 1>), dim3(grid), dim3(256), lds, s, g);
+}
+
+void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
+  MTGV_CHECK(a.M > 0 && a.N > 0 && a.K > 0, ERR_INVALID, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  MTGV_CHECK(a.K % 4 == 0 && a.Cin % 4 == 0 && a.c_total % 4 == 0 && a.c_off % 4 == 0, ERR_INVALID,
+             "gemm: K=%d Cin=%d c_total=%d c_off=%d must be multiples of 4", a.K, a.Cin, a.c_total, a.c_off);
+  MTGV_CHECK(a.K == a.KH * a.KW * a.Cin, ERR_INVALID, "gemm: K=%d != %d*%d*%d", a.K, a.KH, a.KW, a.Cin);
+  MTGV_CHECK(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0, ERR_INVALID, "gemm: operands must be 16-byte aligned");
+  MTGV_CHECK((long)a.M * (long)(a.OH * a.OW > a.hw ? a.OH * a.OW : a.hw) < (1l << 40), ERR_INVALID, "gemm: M too large for fastdiv");
+  const bool conv = !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.stride_w <= 1 && a.pad == 0);
+  const bool apro = a.a_scale != nullptr;
+  MTGV_CHECK(!(apro && conv), ERR_INVALID, "gemm: GRN prologue only on 1x1");
+  if (!conv) MTGV_CHECK(a.OH == a.H && a.OW == a.Wd, ERR_INVALID, "gemm: 1x1 geometry mismatch");
+  if (apro || a.grn_part) MTGV_CHECK(a.hw > 0 && a.M % a.hw == 0, ERR_INVALID, "gemm: hw=%d must divide M=%d", a.hw, a.M);
+  if (a.grn_part) MTGV_CHECK(a.segmax >= gemm_grn_segmax(pl, a.hw), ERR_INVALID, "gemm: segmax too small");
+
+  GemmDev g;
+  g.a = a;
+  g.d_ohw = make_fastdiv((uint32_t)(a.OH * a.OW));
+  g.d_ow = make_fastdiv((uint32_t)a.OW);
+  g.d_cin = make_fastdiv((uint32_t)a.Cin);
+  g.d_kwcin = make_fastdiv((uint32_t)(a.KW * a.Cin));
+  g.d_hw = make_fastdiv((uint32_t)(a.hw > 0 ? a.hw : 1));
+  g.tiles_m = pl.tiles_m;
+  g.tiles_n = pl.tiles_n;
+  g.remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
+  const int grid = pl.tiles_m * pl.tiles_n;
+
+  if (a.topk > 0) {
+    MTGV_CHECK(pl.tm == 1 && pl.tn == 4 && pl.bk == 32 && !conv && !apro, ERR_INVALID, "gemm: top-k epilogue needs the 128x128x32 tile");
+    MTGV_CHECK(a.cand_s != nullptr && a.cand_i != nullptr && a.topk <= 128, ERR_INVALID, "gemm: bad top-k arguments");
+    launch_topk(g, grid, s);
+    HIP_OK(hipGetLastError());
+    return;
+  }
+
+#define MTGV_CASE(TM_, TN_, BK_)                                   \
+  if (pl.tm == TM_ && pl.tn == TN_ && pl.bk == BK_) {              \
+    launch_variant<TM_, TN_, BK_>(g, conv, apro, grid, s);         \
+    HIP_OK(hipGetLastError());                                     \
+    return;                                                        \
+  }
+  MTGV_CASE(1, 1, 16) MTGV_CASE(1, 2, 16) MTGV_CASE(1, 3, 16) MTGV_CASE(1, 4, 16) MTGV_CASE(1, 5, 16)
+  MTGV_CASE(1, 1, 32) MTGV_CASE(1, 2, 32) MTGV_CASE(1, 3, 32) MTGV_CASE(1, 4, 32)
+  MTGV_CASE(2, 2, 16) MTGV_CASE(2, 2, 32)
+#undef MTGV_CASE
+  MTGV_CHECK(false, ERR_INVALID, "gemm: no kernel for tile tm=%d tn=%d bk=%d", pl.tm, pl.tn, pl.bk);
+}
+
+// ---------------------------------------------------------------------------
+// GRN finalize: partials -> per-(image, channel) multiplier.  One block per image.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restrict__ part, int bm, int segmax, int hw, int N,
+                                                          FastDiv d_hw, FastDiv d_bm, const float* __restrict__ gamma,
+                                                          float* __restrict__ scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* gx = sm;        // [N]
+  float* red = sm + N;   // [256]
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int t_first = (int)fdiv((uint32_t)(img * hw), d_bm);
+  const int t_last = (int)fdiv((uint32_t)((img + 1) * hw - 1), d_bm);
+  float local = 0.f;
+  for (int n = tid; n < N; n += 256) {
+    float sum = 0.f;
+    for (int t = t_first; t <= t_last; ++t) {
+      const int seg = img - (int)fdiv((uint32_t)(t * bm), d_hw);
+      sum += part[((long)t * segmax + seg) * N + n];
+    }
+    const float gval = sqrtf(sum);
+    gx[n] = gval;
+    local += gval;
+  }
+  red[tid] = local;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  const float denom = red[0] / (float)N + 1e-6f;
+  for (int n = tid; n < N; n += 256) scale[(long)img * N + n] = gamma[n] * (gx[n] / denom) + 1.0f;
+}
+
+void grn_finalize_launch(const float* part, const GemmPlan& p, int n_img, int hw, int N, const float* gamma, float* scale,
+                         hipStream_t s) {
+  const size_t lds = (size_t)(N + 256) * sizeof(float);
+  MTGV_CHECK(lds <= 160 * 1024, ERR_INVALID, "grn_finalize: N=%d too large", N);
+  hipLaunchKernelGGL(grn_finalize_kernel, dim3(n_img), dim3(256), lds, s, part, p.bm(), gemm_grn_segmax(p, hw), hw, N,
+                     make_fastdiv((uint32_t)hw), make_fastdiv((uint32_t)p.bm()), gamma, scale);
+  HIP_OK(hipGetLastError());
+}
+
+}  // namespace mtgv

@@ -1,0 +1,28 @@
+// Card bank: device-resident L2-normalised vectors + exact cosine top-k.
+#pragma once
+#include "common.h"
+#include "encoder.h"
+
+namespace mtgv {
+
+class Bank {
+ public:
+  Bank(int dim, int64_t capacity);
+  int dim() const { return dim_; }
+  int64_t size() const { return size_; }
+  int64_t capacity() const { return cap_; }
+  void clear() { size_ = 0; }
+  void append(const float* v, int64_t n, bool is_device, hipStream_t s);
+  void set_row(int64_t row, const float* v_host, hipStream_t s);
+  void get_rows(int64_t row, int64_t n, float* out_host) const;
+  void topk(const float* q, int b, int k, int64_t id_base, int64_t* ids, float* scores, hipStream_t s);
+
+ private:
+  int dim_;
+  int64_t cap_, size_ = 0;
+  DevBuf vecs_, qn_, cand_s_, cand_i_;
+};
+
+void topk_merge_launch_i64(float* cs, const int64_t* ci, int b, int ncand, int k, int64_t* ids, float* scores, hipStream_t s);
+
+}  // namespace mtgv

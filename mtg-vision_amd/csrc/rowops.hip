@@ -1,0 +1,395 @@
+// Bandwidth-bound NHWC kernels.  All are one-pass over HBM with 16-byte accesses per lane
+// where the channel count allows; arithmetic is fp32 throughout.
+#include "rowops.h"
+
+namespace mtgv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// LayerNorm over rows.  G lanes cooperate on one row (G = 4..64, power of two),
+// the row is held in registers between the mean, variance and normalise passes.
+// ---------------------------------------------------------------------------
+template <int G, int NV>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ in, int ldi, int i_off, float* __restrict__ out,
+                                                     int ldo, int o_off, const float* __restrict__ w,
+                                                     const float* __restrict__ b, long rows, int C, float eps) {
+  const int tid = threadIdx.x;
+  const long row = (long)blockIdx.x * (256 / G) + tid / G;
+  const int sub = tid % G;
+  const int c4n = C >> 2;
+  const bool rok = row < rows;
+  const float* x = in + (rok ? row : 0) * ldi + i_off;
+  f32x4 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = sub + i * G;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (rok && c4 < c4n) t = *reinterpret_cast<const f32x4*>(x + c4 * 4);
+    v[i] = t;
+    sum += (t[0] + t[1]) + (t[2] + t[3]);
+  }
+#pragma unroll
+  for (int m = G >> 1; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = sub + i * G;
+    if (c4 < c4n) {
+      const f32x4 d = v[i] - mean;
+      sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+#pragma unroll
+  for (int m = G >> 1; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  if (!rok) return;
+  float* y = out + row * ldo + o_off;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = sub + i * G;
+    if (c4 < c4n) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4 * 4);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c4 * 4);
+      *reinterpret_cast<f32x4*>(y + c4 * 4) = (v[i] - mean) * rstd * wv + bv;
+    }
+  }
+}
+
+template <int G, int NV>
+static void ln_go(const float* in, int ldi, int i_off, float* out, int ldo, int o_off, const float* w, const float* b, long rows,
+                  int C, float eps, hipStream_t s) {
+  const long rpb = 256 / G;
+  const long grid = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL((ln_rows_kernel<G, NV>), dim3((unsigned)grid), dim3(256), 0, s, in, ldi, i_off, out, ldo, o_off, w, b, rows,
+                     C, eps);
+}
+
+// any C / any stride: one wave per row, scalar accesses (odd head widths only)
+__global__ __launch_bounds__(256) void ln_rows_scalar_kernel(const float* __restrict__ in, int ldi, int i_off,
+                                                            float* __restrict__ out, int ldo, int o_off,
+                                                            const float* __restrict__ w, const float* __restrict__ b, long rows,
+                                                            int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = in + row * ldi + i_off;
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) sum += x[c];
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = x[c] - mean;
+    sq += d * d;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  float* y = out + row * ldo + o_off;
+  for (int c = lane; c < C; c += 64) y[c] = (x[c] - mean) * rstd * w[c] + b[c];
+}
+
+void ln_rows_launch(const float* in, int ldi, int i_off, float* out, int ldo, int o_off, const float* w, const float* b,
+                    long rows, int C, float eps, hipStream_t s) {
+  if (rows <= 0) return;
+  if (C % 4 != 0 || ldi % 4 != 0 || ldo % 4 != 0 || i_off % 4 != 0 || o_off % 4 != 0) {
+    hipLaunchKernelGGL(ln_rows_scalar_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, ldi, i_off, out, ldo, o_off, w,
+                       b, rows, C, eps);
+    HIP_OK(hipGetLastError());
+    return;
+  }
+  MTGV_CHECK(C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && i_off % 4 == 0 && o_off % 4 == 0, ERR_INVALID,
+             "layernorm: C=%d and strides must be multiples of 4", C);
+  MTGV_CHECK(C <= 64 * 4 * 12, ERR_INVALID, "layernorm: C=%d too wide", C);
+  if (rows <= 0) return;
+  const int c4 = C / 4;
+#define LN_CASE(G_, NV_) ln_go<G_, NV_>(in, ldi, i_off, out, ldo, o_off, w, b, rows, C, eps, s)
+  if (c4 <= 4) LN_CASE(4, 1);
+  else if (c4 <= 8) LN_CASE(8, 1);
+  else if (c4 <= 16) LN_CASE(16, 1);
+  else if (c4 <= 32) LN_CASE(32, 1);
+  else if (c4 <= 64) LN_CASE(64, 1);
+  else if (c4 <= 128) LN_CASE(64, 2);
+  else if (c4 <= 192) LN_CASE(64, 3);
+  else if (c4 <= 256) LN_CASE(64, 4);
+  else if (c4 <= 384) LN_CASE(64, 6);
+  else if (c4 <= 512) LN_CASE(64, 8);
+  else LN_CASE(64, 12);
+#undef LN_CASE
+  HIP_OK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Depthwise 7x7.  A thread owns 4 channels of a strip of TW output pixels along
+// W: each of the 7 input rows is read once into registers (TW+6 float4) and
+// reused by the 7 horizontal taps, so an output costs (TW+6)*7/TW loads
+// instead of 49.  Lanes run over channels (NHWC: contiguous 16 B per lane).
+// ---------------------------------------------------------------------------
+template <int TW>
+__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ w49,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int N, int H, int W,
+                                                     int C, int nstrips, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c4n = C >> 2;
+  const int c4 = (int)(idx % c4n);
+  long t = idx / c4n;
+  const int ws = (int)(t % nstrips);
+  t /= nstrips;
+  const int h = (int)(t % H);
+  const int n = (int)(t / H);
+  const int w0 = ws * TW;
+  const int c = c4 * 4;
+
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+  f32x4 acc[TW];
+#pragma unroll
+  for (int j = 0; j < TW; ++j) acc[j] = bv;
+
+#pragma unroll 1
+  for (int kh = 0; kh < 7; ++kh) {
+    const int ih = h + kh - 3;
+    if (ih < 0 || ih >= H) continue;
+    const float* rowp = in + ((long)(n * H + ih) * W) * C + c;
+    f32x4 r[TW + 6];
+#pragma unroll
+    for (int j = 0; j < TW + 6; ++j) {
+      const int iw = w0 + j - 3;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iw >= 0 && iw < W) v = *reinterpret_cast<const f32x4*>(rowp + (long)iw * C);
+      r[j] = v;
+    }
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w49 + (kh * 7 + kw) * C + c);
+#pragma unroll
+      for (int j = 0; j < TW; ++j) acc[j] += r[j + kw] * wv;
+    }
+  }
+  float* op = out + ((long)(n * H + h) * W + w0) * C + c;
+#pragma unroll
+  for (int j = 0; j < TW; ++j)
+    if (w0 + j < W) *reinterpret_cast<f32x4*>(op + (long)j * C) = acc[j];
+}
+
+void dwconv7_launch(const float* in, const float* w49, const float* bias, float* out, int N, int H, int W, int C,
+                    hipStream_t s) {
+  MTGV_CHECK(C % 4 == 0, ERR_INVALID, "dwconv7: C=%d must be a multiple of 4", C);
+  if (N <= 0) return;
+  const int tw = W >= 8 ? 8 : (W >= 4 ? 4 : 2);
+  const int nstrips = ceil_div(W, tw);
+  const long total = (long)N * H * nstrips * (C / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (tw == 8)
+    hipLaunchKernelGGL((dwconv7_kernel<8>), dim3(grid), dim3(256), 0, s, in, w49, bias, out, N, H, W, C, nstrips, total);
+  else if (tw == 4)
+    hipLaunchKernelGGL((dwconv7_kernel<4>), dim3(grid), dim3(256), 0, s, in, w49, bias, out, N, H, W, C, nstrips, total);
+  else
+    hipLaunchKernelGGL((dwconv7_kernel<2>), dim3(grid), dim3(256), 0, s, in, w49, bias, out, N, H, W, C, nstrips, total);
+  HIP_OK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// layout / dtype conversion at the boundary
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, long HW,
+                                                          int Cp, float scale, float shift, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over N*HW pixels
+  if (idx >= total) return;
+  const long n = idx / HW, p = idx % HW;
+  const float* ip = in + n * C * HW + p;
+  float* op = out + idx * Cp;
+  for (int c = 0; c < Cp; ++c) op[c] = c < C ? __fadd_rn(__fmul_rn(ip[(long)c * HW], scale), shift) : 0.f;
+}
+
+void nchw_to_nhwc_launch(const float* in, float* out, int N, int C, int H, int W, int Cp, float scale, float shift,
+                         hipStream_t s) {
+  const long total = (long)N * H * W;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, C, (long)H * W, Cp,
+                     scale, shift, total);
+  HIP_OK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int C, int Cp,
+                                                       float scale, float shift, int flip, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const uint8_t* ip = in + idx * C;
+  float* op = out + idx * Cp;
+  for (int c = 0; c < Cp; ++c) {
+    float v = 0.f;
+    if (c < C) {
+      const int sc = flip ? (C - 1 - c) : c;
+      v = __fadd_rn(__fmul_rn(__fdiv_rn((float)ip[sc], 255.0f), scale), shift);
+    }
+    op[c] = v;
+  }
+}
+
+void u8_to_f32_launch(const uint8_t* in, float* out, long pixels, int C, int Cp, float scale, float shift, int flip_rgb,
+                      hipStream_t s) {
+  if (pixels <= 0) return;
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, in, out, C, Cp, scale, shift,
+                     flip_rgb, pixels);
+  HIP_OK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void f32hwc_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int Cp,
+                                                          float scale, float shift, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const float* ip = in + idx * C;
+  float* op = out + idx * Cp;
+  for (int c = 0; c < Cp; ++c) {
+    float v = 0.f;
+    if (c < C) v = __fadd_rn(__fmul_rn(fminf(fmaxf(ip[c], 0.f), 1.f), scale), shift);
+    op[c] = v;
+  }
+}
+
+void f32hwc_scale_launch(const float* in, float* out, long pixels, int C, int Cp, float scale, float shift, hipStream_t s) {
+  if (pixels <= 0) return;
+  hipLaunchKernelGGL(f32hwc_scale_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, in, out, C, Cp, scale, shift,
+                     pixels);
+  HIP_OK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// global average pool: block (n, channel chunk), lanes over channels, serial over HW
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int C) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* p = in + (long)n * HW * C + c;
+  float sum = 0.f;
+  for (int i = 0; i < HW; ++i) sum += p[(long)i * C];
+  out[(long)n * C + c] = sum / (float)HW;
+}
+
+void gap_launch(const float* in, float* out, int N, int HW, int C, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(gap_kernel, dim3(ceil_div(C, 256), N), dim3(256), 0, s, in, out, HW, C);
+  HIP_OK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// L2 normalise rows: one wave per row
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = in + row * D;
+  float sq = 0.f;
+  for (int i = lane; i < D; i += 64) sq += x[i] * x[i];
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+  const float nrm = fmaxf(sqrtf(sq), 1e-12f);
+  float* y = out + row * D;
+  for (int i = lane; i < D; i += 64) y[i] = x[i] / nrm;
+}
+
+void l2norm_rows_launch(const float* in, float* out, long rows, int D, hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, out, rows, D);
+  HIP_OK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// YOLO plumbing
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__ in, int ci_total, int ci_off,
+                                                      float* __restrict__ out, int co_total, int co_off, int H, int W, int C,
+                                                      long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over N*H*W*(C/4)
+  if (idx >= total) return;
+  const int c4n = C >> 2;
+  const int c = (int)(idx % c4n) * 4;
+  long t = idx / c4n;
+  const int w = (int)(t % W);
+  t /= W;
+  const int h = (int)(t % H);
+  const long n = t / H;
+  f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int dh = -2; dh <= 2; ++dh) {
+    const int ih = h + dh;
+    if (ih < 0 || ih >= H) continue;
+    for (int dw = -2; dw <= 2; ++dw) {
+      const int iw = w + dw;
+      if (iw < 0 || iw >= W) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((n * H + ih) * W + iw) * ci_total + ci_off + c);
+      m[0] = fmaxf(m[0], v[0]);
+      m[1] = fmaxf(m[1], v[1]);
+      m[2] = fmaxf(m[2], v[2]);
+      m[3] = fmaxf(m[3], v[3]);
+    }
+  }
+  *reinterpret_cast<f32x4*>(out + ((n * H + h) * W + w) * co_total + co_off + c) = m;
+}
+
+void maxpool5_launch(const float* in, int ci_total, int ci_off, float* out, int co_total, int co_off, int N, int H, int W,
+                     int C, hipStream_t s) {
+  MTGV_CHECK(C % 4 == 0 && ci_total % 4 == 0 && ci_off % 4 == 0 && co_total % 4 == 0 && co_off % 4 == 0, ERR_INVALID,
+             "maxpool5: channel counts must be multiples of 4");
+  const long total = (long)N * H * W * (C / 4);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(maxpool5_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, ci_total, ci_off, out,
+                     co_total, co_off, H, W, C, total);
+  HIP_OK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, int ci_total, int ci_off,
+                                                        float* __restrict__ out, int co_total, int co_off, int H, int W, int C,
+                                                        long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over N*2H*2W*(C/4)
+  if (idx >= total) return;
+  const int c4n = C >> 2;
+  const int c = (int)(idx % c4n) * 4;
+  long t = idx / c4n;
+  const int ow = (int)(t % (2 * W));
+  t /= 2 * W;
+  const int oh = (int)(t % (2 * H));
+  const long n = t / (2 * H);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((n * H + (oh >> 1)) * W + (ow >> 1)) * ci_total + ci_off + c);
+  *reinterpret_cast<f32x4*>(out + ((n * 2 * H + oh) * 2 * W + ow) * co_total + co_off + c) = v;
+}
+
+void upsample2x_launch(const float* in, int ci_total, int ci_off, float* out, int co_total, int co_off, int N, int H, int W,
+                       int C, hipStream_t s) {
+  MTGV_CHECK(C % 4 == 0 && ci_total % 4 == 0 && ci_off % 4 == 0 && co_total % 4 == 0 && co_off % 4 == 0, ERR_INVALID,
+             "upsample2x: channel counts must be multiples of 4");
+  const long total = (long)N * 2 * H * 2 * W * (C / 4);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, ci_total, ci_off, out,
+                     co_total, co_off, H, W, C, total);
+  HIP_OK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ in, int ci_total, int ci_off,
+                                                           float* __restrict__ out, int co_total, int co_off, int C, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over pixels*(C/4)
+  if (idx >= total) return;
+  const int c4n = C >> 2;
+  const int c = (int)(idx % c4n) * 4;
+  const long p = idx / c4n;
+  *reinterpret_cast<f32x4*>(out + p * co_total + co_off + c) = *reinterpret_cast<const f32x4*>(in + p * ci_total + ci_off + c);
+}
+
+void copy_channels_launch(const float* in, int ci_total, int ci_off, float* out, int co_total, int co_off, long pixels, int C,
+                          hipStream_t s) {
+  MTGV_CHECK(C % 4 == 0 && ci_total % 4 == 0 && ci_off % 4 == 0 && co_total % 4 == 0 && co_off % 4 == 0, ERR_INVALID,
+             "copy_channels: channel counts must be multiples of 4");
+  const long total = pixels * (C / 4);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, ci_total, ci_off, out,
+                     co_total, co_off, C, total);
+  HIP_OK(hipGetLastError());
+}
+
+}  // namespace mtgv

@@ -1,0 +1,109 @@
+"""GPU parity of the HIP encoder against the golden vectors captured from the reference and the CPU oracle."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # BASELINE.json north_star: fp32 embeddings within 1e-4 of the PyTorch CPU path
+
+MICRO = ["micro_ae_conv_linear", "micro_ae_conv_mlp", "micro_ae_conv_act_mlp", "micro_ae_pool_linear", "micro_ae_pool_mlp", "micro_plain", "micro_ae_ragged"]
+FULL = ["ae_nano_192x128", "ae_tiny_192x128", "ae_tiny_224_z784", "plain_tiny_224"]
+
+
+def _cfg(npz):
+    from mtgv import spec
+
+    d = ast.literal_eval(str(npz["cfg"]))
+    return spec.EncoderConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items()})
+
+
+@pytest.mark.parametrize("name", MICRO)
+def test_micro_stages_and_z(name):
+    from mtgv import spec
+    from mtgv.encoder import Encoder
+
+    g = np.load(os.path.join(GOLDEN, f"encoder_{name}.npz"))
+    cfg = _cfg(g)
+    enc = Encoder(cfg, spec.random_encoder_state(cfg, 1), max_batch=4)
+    enc.set_capture(True)
+    z = enc.encode(torch.from_numpy(g["x"])).cpu().numpy()
+    for s in range(4):
+        got = enc.stage_output(s, 3).cpu().numpy().transpose(0, 3, 1, 2)
+        err = np.abs(got - g[f"stage{s}"]).max()
+        assert err < TOL, f"stage {s}: {err}"
+    assert np.abs(z - g["z_fp64"]).max() < TOL
+    assert np.abs(z - g["z_fp32"]).max() < TOL
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_full_config_z(name):
+    from mtgv import spec
+    from mtgv.encoder import Encoder
+
+    g = np.load(os.path.join(GOLDEN, f"encoder_{name}.npz"))
+    cfg = _cfg(g)
+    enc = Encoder(cfg, spec.random_encoder_state(cfg, 1), max_batch=4)
+    x = np.random.default_rng(0).random((4, 3, *cfg.image_hw), dtype=np.float32)
+    z = enc.encode(torch.from_numpy(x)).cpu().numpy()
+    assert z.shape == (4, cfg.z_size)
+    e64 = np.abs(z - g["z_fp64"]).max()
+    e32 = np.abs(z - g["z_fp32"]).max()
+    print(f"{name}: max|z - ref_fp64| = {e64:.3e}, max|z - ref_fp32| = {e32:.3e}")
+    assert e64 < TOL and e32 < TOL
+
+
+def test_batching_layouts_and_predict():
+    """batch > max_batch is chunked; NCHW f32 / NHWC f32 / NHWC u8 inputs agree; predict() contract."""
+    from mtgv import spec
+    from mtgv.encoder import Encoder
+    from oracle import encoder_ref as R
+
+    cfg = spec.EncoderConfig("ae", (96, 64), 3, 48, (1, 1, 2, 1), (8, 16, 32, 64), "conv+linear", True)
+    sd = spec.random_encoder_state(cfg, 1)
+    enc = Encoder(cfg, sd, max_batch=3)
+    rng = np.random.default_rng(9)
+    u8 = rng.integers(0, 256, (7, 96, 64, 3), dtype=np.uint8)
+    z_u8 = enc.encode(u8).cpu().numpy()
+    f = (u8.astype(np.float32) / 255.0).astype(np.float32)
+    z_nhwc = enc.encode(torch.from_numpy(f)).cpu().numpy()
+    z_nchw = enc.encode(torch.from_numpy(f.transpose(0, 3, 1, 2).copy())).cpu().numpy()
+    ref = R.encoder_forward(sd, cfg, f.transpose(0, 3, 1, 2)).numpy()
+    for z in (z_u8, z_nhwc, z_nchw):
+        assert np.abs(z - ref).max() < TOL
+    np.testing.assert_array_equal(z_u8, z_nhwc)
+    one = enc.predict(u8[2])
+    assert one.shape == (48,) and one.dtype == np.float32
+    assert np.abs(one - R.predict_hwc(sd, cfg, u8[2])).max() < TOL
+    assert enc.input_hwc == (96, 64, 3)
+    assert enc.ran_forward().shape == (48,)
+    assert enc.encode(np.zeros((0, 96, 64, 3), np.uint8)).shape == (0, 48)
+    with pytest.raises(AssertionError):
+        enc.predict(np.zeros((96, 64), np.float32))
+    with pytest.raises(AssertionError):
+        enc.encode(torch.zeros(2, 3, 64, 64))
+
+
+def test_checkpoint_prefix_and_missing_keys():
+    from mtgv import spec
+    from mtgv.encoder import Encoder
+
+    cfg = spec.EncoderConfig("ae", (64, 64), 3, 16, (1, 1, 1, 1), (8, 16, 32, 64), "pool+linear", True)
+    sd = spec.random_encoder_state(cfg, 3)
+    lightning = {f"model.encoder.{k}": torch.from_numpy(v) for k, v in sd.items()}
+    lightning["model.decoder.stem.weight"] = torch.zeros(3)
+    a = Encoder(cfg, sd, max_batch=2)
+    b = Encoder(cfg, lightning, max_batch=2)
+    x = torch.rand(2, 3, 64, 64)
+    np.testing.assert_array_equal(a.encode(x).cpu().numpy(), b.encode(x).cpu().numpy())
+    broken = dict(sd)
+    broken.pop("head.bias")
+    with pytest.raises(KeyError):
+        Encoder(cfg, broken, max_batch=2)
+    with pytest.raises(RuntimeError):
+        Encoder(cfg, None, max_batch=2).encode(x)  # forward before weights are loaded
