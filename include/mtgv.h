@@ -141,10 +141,12 @@ MTGV_API int mtgv_detector_finalize(mtgv_detector* h);
  * Outputs (device): n_det (n) int32; per frame up to max_det rows of
  *   boxes (n, max_det, 4) xyxy pixels, conf (n, max_det), cls (n, max_det) int32,
  *   keep_idx (n, max_det) int32 anchor index in [0, 8400),
- *   mask_logits (n, max_det, 160, 160) or NULL to skip. */
+ *   mask_logits (n, mask_rows, 160, 160): coeffs @ protos cropped to the box (process_mask before
+ *   the upsample) for the first min(n_det, mask_rows) detections of each frame; rows beyond
+ *   n_det are left untouched; NULL skips the mask stage. */
 MTGV_API int mtgv_detector_forward(mtgv_detector* h, const uint8_t* frames_dev, int32_t n, int32_t flip_rgb,
                                    int32_t* n_det_dev, float* boxes_dev, float* conf_dev, int32_t* cls_dev,
-                                   int32_t* keep_idx_dev, float* mask_logits_dev, void* stream);
+                                   int32_t* keep_idx_dev, float* mask_logits_dev, int32_t mask_rows, void* stream);
 /* raw head outputs of the last forward: pred (n, 4+nc+32, 8400) and protos (n, 32, 160, 160) */
 MTGV_API int mtgv_detector_raw(mtgv_detector* h, int32_t n, float* pred_dev, float* protos_dev, void* stream);
 MTGV_API int mtgv_detector_flops(const mtgv_detector* h, double* flops_per_frame);
@@ -161,10 +163,11 @@ MTGV_API size_t mtgv_nms_workspace_bytes(int32_t n, int32_t na);
 /* ------------------------------------------------------------------------- */
 /* frames_dev (nf, fh, fw, 3) uint8; quads_dev (nq, 4, 2) float32 source corners (x,y) in the
  * order dst corners [[0,0],[w,0],[w,h],[0,h]] are matched to; frame_idx_dev (nq) int32.
- * out_dev (nq, out_h, out_w, 3) uint8. */
+ * out_dev (nq, out_h, out_w, 3) uint8.  workspace_dev: mtgv_warp_workspace_bytes(nq) bytes. */
+MTGV_API size_t mtgv_warp_workspace_bytes(int32_t nq);
 MTGV_API int mtgv_warp_quads(const uint8_t* frames_dev, int32_t nf, int32_t fh, int32_t fw, const float* quads_dev,
-                             const int32_t* frame_idx_dev, int32_t nq, int32_t out_h, int32_t out_w, float expand_ratio,
-                             uint8_t* out_dev, void* stream);
+                             const int32_t* frame_idx_dev, int32_t nq, int32_t out_h, int32_t out_w, double expand_ratio,
+                             uint8_t* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Single ops (unit-test and composition surface; same kernels the handles use) */

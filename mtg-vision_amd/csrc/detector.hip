@@ -1,0 +1,589 @@
+// YOLOv8n-seg forward on the GPU, NHWC fp32.  Module graph: ultralytics yolov8-seg.yaml at
+// scale "n" (third-party to the reference; call site mtgvision/od_export.py:141-160, model
+// family od_train.py:46-70).  BatchNorm (eps 1e-3) is folded into the conv weights at
+// finalize(); Concat is free (producers write channel slices of the consumer's buffer);
+// every Conv+SiLU is one launch of the f32-MFMA implicit GEMM (gemm_f32.hip).
+#include "detector.h"
+#include "nms.h"
+#include "rowops.h"
+
+#include <math.h>
+
+namespace mtgv {
+
+static int make_div8(double v) { return (int)(ceil(v / 8.0) * 8.0); }
+static int chn(int c) { return make_div8(std::min(c, 1024) * 0.25); }
+static int rep(int n) { return n > 1 ? std::max((int)lround(n * 0.33), 1) : n; }
+
+// ---------------------------------------------------------------------------
+// decode: DFL expectation -> ltrb -> xywh * stride; class sigmoid; coefficient copy
+// rawhead rows: [0,64) box logits (4 sides x 16 bins), [64,64+nc) class logits, [68,100) coeffs
+// ---------------------------------------------------------------------------
+static constexpr int RAW_CT = 100, RAW_CLS = 64, RAW_COEF = 68;
+
+__global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ r0, const float* __restrict__ r1,
+                                                    const float* __restrict__ r2, float* __restrict__ pred, int n, int nc, int nm,
+                                                    int imgsz, int na) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)n * na) return;
+  const int img = (int)(idx / na), a = (int)(idx % na);
+  const int w0 = imgsz / 8, w1 = imgsz / 16, w2 = imgsz / 32;
+  const int n0 = w0 * w0, n1 = w1 * w1;
+  const float* row;
+  int gw, pix;
+  float stride;
+  if (a < n0) {
+    pix = a, gw = w0, stride = 8.f;
+    row = r0 + ((long)img * n0 + pix) * RAW_CT;
+  } else if (a < n0 + n1) {
+    pix = a - n0, gw = w1, stride = 16.f;
+    row = r1 + ((long)img * n1 + pix) * RAW_CT;
+  } else {
+    pix = a - n0 - n1, gw = w2, stride = 32.f;
+    row = r2 + ((long)img * w2 * w2 + pix) * RAW_CT;
+  }
+  float d[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float v[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[i] = row[s * 16 + i];
+      mx = fmaxf(mx, v[i]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[i] = expf(v[i] - mx);
+      sum += v[i];
+    }
+    float e = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e += (v[i] / sum) * (float)i;
+    d[s] = e;
+  }
+  const float ax = (float)(pix % gw) + 0.5f, ay = (float)(pix / gw) + 0.5f;
+  const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+  float* P = pred + (long)img * (4 + nc + nm) * na + a;
+  P[0] = (x1 + x2) / 2.f * stride;
+  P[(long)na] = (y1 + y2) / 2.f * stride;
+  P[(long)2 * na] = (x2 - x1) * stride;
+  P[(long)3 * na] = (y2 - y1) * stride;
+  for (int c = 0; c < nc; ++c) P[(long)(4 + c) * na] = 1.0f / (1.0f + expf(-row[RAW_CLS + c]));
+  for (int c = 0; c < nm; ++c) P[(long)(4 + nc + c) * na] = row[RAW_COEF + c];
+}
+
+// NHWC -> NCHW (raw protos for parity tests)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, long HW,
+                                                          long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over N*C*HW (output order)
+  if (idx >= total) return;
+  const long p = idx % HW;
+  const long t = idx / HW;
+  const int c = (int)(t % C);
+  const long n = t / C;
+  out[idx] = in[(n * HW + p) * C + c];
+}
+
+// ---------------------------------------------------------------------------
+// construction: expected ultralytics keys
+// ---------------------------------------------------------------------------
+void Detector::expect(const std::string& key, std::vector<int> shape) {
+  Raw r;
+  r.shape = shape;
+  raw_[key] = r;
+}
+void Detector::expect_conv_bn(const std::string& p, int cout, int cin, int k) {
+  expect(p + ".conv.weight", {cout, cin, k, k});
+  expect(p + ".bn.weight", {cout});
+  expect(p + ".bn.bias", {cout});
+  expect(p + ".bn.running_mean", {cout});
+  expect(p + ".bn.running_var", {cout});
+}
+
+Detector::Detector(const mtgv_detector_cfg& cfg) : cfg_(cfg) {
+  MTGV_CHECK(cfg.nc >= 1 && cfg.nc <= 4, ERR_INVALID, "detector: nc=%d (1..4 supported)", cfg.nc);
+  MTGV_CHECK(cfg.imgsz > 0 && cfg.imgsz % 32 == 0, ERR_INVALID, "detector: imgsz=%d must be a multiple of 32", cfg.imgsz);
+  MTGV_CHECK(cfg.max_batch > 0, ERR_INVALID, "detector: max_batch=%d", cfg.max_batch);
+  MTGV_CHECK(cfg.max_det > 0 && cfg.max_det <= 1024, ERR_INVALID, "detector: max_det=%d", cfg.max_det);
+  const int S = cfg.imgsz;
+  na_ = (S / 8) * (S / 8) + (S / 16) * (S / 16) + (S / 32) * (S / 32);
+
+  auto P = [](int i) { return "model." + std::to_string(i); };
+  // backbone + neck
+  struct L { int idx; char kind; int cout, n; bool sc; };  // kind: c conv, f c2f, s sppf
+  const L layers[] = {{0, 'c', chn(64), 0, false},   {1, 'c', chn(128), 0, false},  {2, 'f', chn(128), rep(3), true},
+                      {3, 'c', chn(256), 0, false},  {4, 'f', chn(256), rep(6), true}, {5, 'c', chn(512), 0, false},
+                      {6, 'f', chn(512), rep(6), true}, {7, 'c', chn(1024), 0, false}, {8, 'f', chn(1024), rep(3), true},
+                      {9, 's', chn(1024), 0, false}, {12, 'f', chn(512), rep(3), false}, {15, 'f', chn(256), rep(3), false},
+                      {16, 'c', chn(256), 0, false}, {18, 'f', chn(512), rep(3), false}, {19, 'c', chn(512), 0, false},
+                      {21, 'f', chn(1024), rep(3), false}};
+  std::map<int, int> in_ch = {{0, 3},   {1, chn(64)},   {2, chn(128)},  {3, chn(128)},
+                              {4, chn(256)}, {5, chn(256)},  {6, chn(512)},  {7, chn(512)},
+                              {8, chn(1024)}, {9, chn(1024)}, {12, chn(1024) + chn(512)}, {15, chn(512) + chn(256)},
+                              {16, chn(256)}, {18, chn(256) + chn(512)}, {19, chn(512)}, {21, chn(512) + chn(1024)}};
+  for (const L& l : layers) {
+    const int cin = in_ch[l.idx];
+    if (l.kind == 'c') {
+      expect_conv_bn(P(l.idx), l.cout, cin, 3);
+    } else if (l.kind == 'f') {
+      const int ch = l.cout / 2;
+      expect_conv_bn(P(l.idx) + ".cv1", 2 * ch, cin, 1);
+      expect_conv_bn(P(l.idx) + ".cv2", l.cout, (2 + l.n) * ch, 1);
+      for (int j = 0; j < l.n; ++j) {
+        expect_conv_bn(P(l.idx) + ".m." + std::to_string(j) + ".cv1", ch, ch, 3);
+        expect_conv_bn(P(l.idx) + ".m." + std::to_string(j) + ".cv2", ch, ch, 3);
+      }
+      c2f_[l.idx] = {l.cout, l.n, l.sc, cin};
+    } else {
+      expect_conv_bn(P(l.idx) + ".cv1", cin / 2, cin, 1);
+      expect_conv_bn(P(l.idx) + ".cv2", l.cout, cin / 2 * 4, 1);
+    }
+  }
+  const int chs[3] = {chn(256), chn(512), chn(1024)};
+  const int c2 = std::max(std::max(16, chs[0] / 4), reg_max_ * 4);
+  const int c3 = std::max(chs[0], std::min(cfg.nc, 100));
+  const int c4 = std::max(chs[0] / 4, nm_);
+  MTGV_CHECK(c2 == 64 && c3 == 64 && c4 == 32, ERR_INVALID, "detector: unexpected head widths");
+  const std::string H = "model.22";
+  for (int l = 0; l < 3; ++l) {
+    const std::string ls = std::to_string(l);
+    expect_conv_bn(H + ".cv2." + ls + ".0", c2, chs[l], 3);
+    expect_conv_bn(H + ".cv2." + ls + ".1", c2, c2, 3);
+    expect(H + ".cv2." + ls + ".2.weight", {4 * reg_max_, c2, 1, 1});
+    expect(H + ".cv2." + ls + ".2.bias", {4 * reg_max_});
+    expect_conv_bn(H + ".cv3." + ls + ".0", c3, chs[l], 3);
+    expect_conv_bn(H + ".cv3." + ls + ".1", c3, c3, 3);
+    expect(H + ".cv3." + ls + ".2.weight", {cfg.nc, c3, 1, 1});
+    expect(H + ".cv3." + ls + ".2.bias", {cfg.nc});
+    expect_conv_bn(H + ".cv4." + ls + ".0", c4, chs[l], 3);
+    expect_conv_bn(H + ".cv4." + ls + ".1", c4, c4, 3);
+    expect(H + ".cv4." + ls + ".2.weight", {nm_, c4, 1, 1});
+    expect(H + ".cv4." + ls + ".2.bias", {nm_});
+  }
+  expect(H + ".dfl.conv.weight", {1, reg_max_, 1, 1});
+  expect_conv_bn(H + ".proto.cv1", npr_, chs[0], 3);
+  expect(H + ".proto.upsample.weight", {npr_, npr_, 2, 2});
+  expect(H + ".proto.upsample.bias", {npr_});
+  expect_conv_bn(H + ".proto.cv2", npr_, npr_, 3);
+  expect_conv_bn(H + ".proto.cv3", nm_, npr_, 1);
+}
+
+Detector::~Detector() {
+  for (float* p : dev_allocs_) (void)hipFree(p);
+  if (nms_ws_) (void)hipFree(nms_ws_);
+}
+
+void Detector::set_param(const char* key, const float* host, int64_t numel) {
+  auto it = raw_.find(key);
+  MTGV_CHECK(it != raw_.end(), ERR_KEY, "unknown detector parameter key '%s'", key);
+  int64_t want = 1;
+  for (int d : it->second.shape) want *= d;
+  MTGV_CHECK(numel == want, ERR_INVALID, "parameter %s: got %lld elements, expected %lld", key, (long long)numel, (long long)want);
+  it->second.data.assign(host, host + numel);
+  it->second.set = true;
+  finalized_ = false;
+}
+
+int Detector::missing() const {
+  int m = 0;
+  for (auto& kv : raw_) m += kv.second.set ? 0 : 1;
+  return m;
+}
+
+float* Detector::upload(const std::vector<float>& v) {
+  float* d = nullptr;
+  HIP_OK(hipMalloc((void**)&d, std::max<size_t>(v.size(), 4) * sizeof(float)));
+  HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  dev_allocs_.push_back(d);
+  return d;
+}
+
+// Conv2d(bias=False) + BatchNorm2d(eps=1e-3) -> weight [cout][k][k][cin_pad], bias [cout]
+ConvW Detector::fold(const std::string& p, int cin_pad) {
+  const Raw& w = raw_.at(p + ".conv.weight");
+  const int cout = w.shape[0], cin = w.shape[1], k = w.shape[2];
+  const int cp = cin_pad > 0 ? cin_pad : cin;
+  const auto& g = raw_.at(p + ".bn.weight").data;
+  const auto& b = raw_.at(p + ".bn.bias").data;
+  const auto& mu = raw_.at(p + ".bn.running_mean").data;
+  const auto& var = raw_.at(p + ".bn.running_var").data;
+  std::vector<float> wf((size_t)cout * k * k * cp, 0.f), bf(cout);
+  for (int o = 0; o < cout; ++o) {
+    const double sc = (double)g[o] / sqrt((double)var[o] + 1e-3);
+    bf[o] = (float)((double)b[o] - (double)mu[o] * sc);
+    for (int i = 0; i < cin; ++i)
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw)
+          wf[(((size_t)o * k + kh) * k + kw) * cp + i] = (float)((double)w.data[(((size_t)o * cin + i) * k + kh) * k + kw] * sc);
+  }
+  ConvW c;
+  c.w = upload(wf), c.b = upload(bf), c.cout = cout, c.cin = cp, c.k = k;
+  return c;
+}
+
+ConvW Detector::plain(const std::string& p) {
+  const Raw& w = raw_.at(p + ".weight");
+  const int cout = w.shape[0], cin = w.shape[1], k = w.shape[2];
+  std::vector<float> wf((size_t)cout * k * k * cin);
+  for (int o = 0; o < cout; ++o)
+    for (int i = 0; i < cin; ++i)
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw)
+          wf[(((size_t)o * k + kh) * k + kw) * cin + i] = w.data[(((size_t)o * cin + i) * k + kh) * k + kw];
+  ConvW c;
+  c.w = upload(wf), c.b = upload(raw_.at(p + ".bias").data), c.cout = cout, c.cin = cin, c.k = k;
+  return c;
+}
+
+View Detector::take(int n, int h, int w, int c) {
+  const size_t fl = ((size_t)n * h * w * c + 63) / 64 * 64;
+  MTGV_CHECK(arena_used_ + fl <= arena_.n, ERR_RUNTIME, "detector arena exhausted");
+  View v;
+  v.p = arena_.p + arena_used_;
+  v.H = h, v.W = w, v.ct = c, v.co = 0, v.C = c;
+  arena_used_ += fl;
+  return v;
+}
+
+void Detector::finalize() {
+  MTGV_CHECK(missing() == 0, ERR_RUNTIME, "detector has %d unset parameters", missing());
+  if (finalized_) return;
+  for (float* p : dev_allocs_) (void)hipFree(p);
+  dev_allocs_.clear();
+  cw_.clear();
+  // every Conv+BN key prefix
+  for (auto& kv : raw_) {
+    const std::string& k = kv.first;
+    const std::string suf = ".conv.weight";
+    if (k.size() > suf.size() && k.compare(k.size() - suf.size(), suf.size(), suf) == 0) {
+      const std::string pre = k.substr(0, k.size() - suf.size());
+      cw_[pre] = fold(pre, pre == "model.0" ? 4 : 0);
+    }
+  }
+  const std::string H = "model.22";
+  for (int l = 0; l < 3; ++l) {
+    const std::string ls = std::to_string(l);
+    // the three branches' first 3x3 convs read the same input: one conv with 64+64+32 outputs
+    const ConvW &a = cw_.at(H + ".cv2." + ls + ".0"), &b = cw_.at(H + ".cv3." + ls + ".0"), &c = cw_.at(H + ".cv4." + ls + ".0");
+    const size_t per = (size_t)9 * a.cin;
+    std::vector<float> w((size_t)(a.cout + b.cout + c.cout) * per), bias(a.cout + b.cout + c.cout);
+    size_t wo = 0, bo = 0;
+    for (const ConvW* q : {&a, &b, &c}) {
+      HIP_OK(hipMemcpy(w.data() + wo, q->w, (size_t)q->cout * per * sizeof(float), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(bias.data() + bo, q->b, (size_t)q->cout * sizeof(float), hipMemcpyDeviceToHost));
+      wo += (size_t)q->cout * per, bo += q->cout;
+    }
+    head_first_[l].w = upload(w), head_first_[l].b = upload(bias);
+    head_first_[l].cout = a.cout + b.cout + c.cout, head_first_[l].cin = a.cin, head_first_[l].k = 3;
+    head_box2_[l] = cw_.at(H + ".cv2." + ls + ".1");
+    head_cls2_[l] = cw_.at(H + ".cv3." + ls + ".1");
+    head_coef2_[l] = cw_.at(H + ".cv4." + ls + ".1");
+    head_box3_[l] = plain(H + ".cv2." + ls + ".2");
+    head_cls3_[l] = plain(H + ".cv3." + ls + ".2");
+    head_coef3_[l] = plain(H + ".cv4." + ls + ".2");
+  }
+  // DFL weights must be arange(16) (they are a fixed buffer upstream); the decode kernel hard-codes them
+  {
+    const auto& d = raw_.at(H + ".dfl.conv.weight").data;
+    for (int i = 0; i < reg_max_; ++i) MTGV_CHECK(d[i] == (float)i, ERR_INVALID, "dfl.conv.weight is not arange(16)");
+  }
+  // ConvTranspose2d(k2,s2): weight (in, out, kh, kw) -> four [out][in] matrices
+  {
+    const Raw& w = raw_.at(H + ".proto.upsample.weight");
+    const int ci = w.shape[0], co = w.shape[1];
+    float* bias = upload(raw_.at(H + ".proto.upsample.bias").data);
+    for (int kh = 0; kh < 2; ++kh)
+      for (int kw = 0; kw < 2; ++kw) {
+        std::vector<float> m((size_t)co * ci);
+        for (int o = 0; o < co; ++o)
+          for (int i = 0; i < ci; ++i) m[(size_t)o * ci + i] = w.data[(((size_t)i * co + o) * 2 + kh) * 2 + kw];
+        ConvW c;
+        c.w = upload(m), c.b = bias, c.cout = co, c.cin = ci, c.k = 1;
+        proto_up_[kh * 2 + kw] = c;
+      }
+  }
+
+  // activation arena for max_batch
+  const int nb = cfg_.max_batch, S = cfg_.imgsz;
+  const int s2 = S / 2, s4 = S / 4, s8 = S / 8, s16 = S / 16, s32 = S / 32;
+  const int c16 = chn(64), c32 = chn(128), c64 = chn(256), c128 = chn(512), c256 = chn(1024);
+  size_t total = 0;
+  auto sz = [&](int h, int w, int c) { total += ((size_t)nb * h * w * c + 63) / 64 * 64; };
+  sz(S, S, 4), sz(s2, s2, c16), sz(s4, s4, c32);
+  sz(s4, s4, 3 * c32 / 2), sz(s4, s4, c32 / 2), sz(s4, s4, c32);       // node 2
+  sz(s8, s8, c64);                                                      // 3
+  sz(s8, s8, 4 * c64 / 2), sz(s8, s8, c64 / 2);                         // 4
+  sz(s8, s8, c128 + c64);                                               // cat14
+  sz(s16, s16, c128);                                                   // 5
+  sz(s16, s16, 4 * c128 / 2), sz(s16, s16, c128 / 2);                   // 6
+  sz(s16, s16, c256 + c128);                                            // cat11
+  sz(s32, s32, c256);                                                   // 7
+  sz(s32, s32, 3 * c256 / 2), sz(s32, s32, c256 / 2), sz(s32, s32, c256);  // 8
+  sz(s32, s32, 2 * c256);                                               // sppcat
+  sz(s32, s32, c128 + c256);                                            // cat20
+  sz(s16, s16, 3 * c128 / 2), sz(s16, s16, c128 / 2);                   // 12
+  sz(s16, s16, c64 + c128);                                             // cat17
+  sz(s8, s8, 3 * c64 / 2), sz(s8, s8, c64 / 2), sz(s8, s8, c64);        // 15, p3
+  sz(s16, s16, 3 * c128 / 2), sz(s16, s16, c128 / 2), sz(s16, s16, c128);  // 18, p4
+  sz(s32, s32, 3 * c256 / 2), sz(s32, s32, c256 / 2), sz(s32, s32, c256);  // 21, p5
+  sz(s8, s8, 160), sz(s8, s8, 160);                                     // head t1/t2 (largest level)
+  sz(s8, s8, RAW_CT), sz(s16, s16, RAW_CT), sz(s32, s32, RAW_CT);       // rawhead
+  sz(s8, s8, npr_), sz(s4, s4, npr_), sz(s4, s4, npr_), sz(s4, s4, nm_);  // proto
+  sz(1, na_, 4 + cfg_.nc + nm_);                                        // pred
+  sz(1, cfg_.max_det, nm_);                                             // coef
+  arena_.alloc(total + 1024);
+  arena_used_ = 0;
+  v_.clear();
+  v_["x0"] = take(nb, S, S, 4);
+  v_["l0"] = take(nb, s2, s2, c16);
+  v_["l1"] = take(nb, s4, s4, c32);
+  v_["cat2"] = take(nb, s4, s4, 3 * c32 / 2), v_["tmp2"] = take(nb, s4, s4, c32 / 2), v_["l2"] = take(nb, s4, s4, c32);
+  v_["l3"] = take(nb, s8, s8, c64);
+  v_["cat4"] = take(nb, s8, s8, 4 * c64 / 2), v_["tmp4"] = take(nb, s8, s8, c64 / 2);
+  v_["cat14"] = take(nb, s8, s8, c128 + c64);
+  v_["l5"] = take(nb, s16, s16, c128);
+  v_["cat6"] = take(nb, s16, s16, 4 * c128 / 2), v_["tmp6"] = take(nb, s16, s16, c128 / 2);
+  v_["cat11"] = take(nb, s16, s16, c256 + c128);
+  v_["l7"] = take(nb, s32, s32, c256);
+  v_["cat8"] = take(nb, s32, s32, 3 * c256 / 2), v_["tmp8"] = take(nb, s32, s32, c256 / 2), v_["l8"] = take(nb, s32, s32, c256);
+  v_["sppcat"] = take(nb, s32, s32, 2 * c256);
+  v_["cat20"] = take(nb, s32, s32, c128 + c256);
+  v_["cat12"] = take(nb, s16, s16, 3 * c128 / 2), v_["tmp12"] = take(nb, s16, s16, c128 / 2);
+  v_["cat17"] = take(nb, s16, s16, c64 + c128);
+  v_["cat15"] = take(nb, s8, s8, 3 * c64 / 2), v_["tmp15"] = take(nb, s8, s8, c64 / 2), v_["p3"] = take(nb, s8, s8, c64);
+  v_["cat18"] = take(nb, s16, s16, 3 * c128 / 2), v_["tmp18"] = take(nb, s16, s16, c128 / 2), v_["p4"] = take(nb, s16, s16, c128);
+  v_["cat21"] = take(nb, s32, s32, 3 * c256 / 2), v_["tmp21"] = take(nb, s32, s32, c256 / 2), v_["p5"] = take(nb, s32, s32, c256);
+  v_["t1"] = take(nb, s8, s8, 160), v_["t2"] = take(nb, s8, s8, 160);
+  rawhead_[0] = take(nb, s8, s8, RAW_CT).p, rawhead_[1] = take(nb, s16, s16, RAW_CT).p, rawhead_[2] = take(nb, s32, s32, RAW_CT).p;
+  v_["pr1"] = take(nb, s8, s8, npr_), v_["pr2"] = take(nb, s4, s4, npr_), v_["pr3"] = take(nb, s4, s4, npr_);
+  v_["protos"] = take(nb, s4, s4, nm_);
+  pred_ = take(nb, 1, na_, 4 + cfg_.nc + nm_).p;
+  coef_ = take(nb, 1, cfg_.max_det, nm_).p;
+  // rawhead class padding column (index 67) is never written by a conv; keep it defined
+  HIP_OK(hipMemset(arena_.p, 0, arena_.n * sizeof(float)));
+  if (nms_ws_) (void)hipFree(nms_ws_);
+  nms_ws_bytes_ = nms_workspace_bytes(nb, na_);
+  HIP_OK(hipMalloc((void**)&nms_ws_, nms_ws_bytes_));
+  finalized_ = true;
+
+  // algorithmic FLOPs of one frame: run the plan once in counting mode
+  count_flops_ = true;
+  flops_ = 0;
+  forward(nullptr, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+  count_flops_ = false;
+}
+
+void Detector::conv(const ConvW& w, const View& in, const View& out, int stride, int act, const View* res, int n, hipStream_t s) {
+  MTGV_CHECK(in.C == w.cin && out.C == w.cout, ERR_RUNTIME, "detector: conv channel mismatch (%d->%d vs %d->%d)", in.C, out.C, w.cin,
+             w.cout);
+  GemmArgs g;
+  g.A = in.p, g.W = w.w, g.bias = w.b, g.Out = out.p;
+  g.M = n * out.H * out.W, g.N = w.cout, g.K = w.k * w.k * w.cin;
+  g.H = in.H, g.Wd = in.W, g.c_total = in.ct, g.c_off = in.co, g.Cin = in.C;
+  g.KH = w.k, g.KW = w.k, g.stride = stride, g.pad = w.k / 2;
+  g.OH = out.H, g.OW = out.W, g.OH2 = out.H, g.OW2 = out.W;
+  g.ldo = out.ct, g.o_off = out.co;
+  g.act = act;
+  if (res) g.res = res->p + res->co, g.ldr = res->ct;
+  if (count_flops_) {
+    // model.0 is stored with a zero 4th input channel; count the real 3
+    const double kk = (&w == &cw_.at("model.0")) ? 27.0 : (double)g.K;
+    flops_ += 2.0 * g.M * g.N * kk;
+    return;
+  }
+  gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+}
+
+// C2f: cv1 -> 2 chunks; n bottlenecks (3x3,3x3, +shortcut) each appended; cv2 over the concat
+void Detector::c2f(int idx, const View& in, const View& out, int n, hipStream_t s) {
+  const C2fInfo& ci = c2f_.at(idx);
+  const int ch = ci.cout / 2;
+  const std::string P = "model." + std::to_string(idx);
+  const View cat = v_.at("cat" + std::to_string(idx));
+  const View tmp = v_.at("tmp" + std::to_string(idx));
+  conv(cw_.at(P + ".cv1"), in, cat.slice(0, 2 * ch), 1, ACT_SILU, nullptr, n, s);
+  for (int j = 0; j < ci.n; ++j) {
+    const View src = cat.slice((1 + j) * ch, ch);
+    const View dst = cat.slice((2 + j) * ch, ch);
+    const std::string M = P + ".m." + std::to_string(j);
+    conv(cw_.at(M + ".cv1"), src, tmp, 1, ACT_SILU, nullptr, n, s);
+    conv(cw_.at(M + ".cv2"), tmp, dst, 1, ACT_SILU, ci.shortcut ? &src : nullptr, n, s);
+  }
+  conv(cw_.at(P + ".cv2"), cat.slice(0, (2 + ci.n) * ch), out, 1, ACT_SILU, nullptr, n, s);
+}
+
+void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float* boxes, float* conf, int* cls, int* keep_idx,
+                       float* mask_logits, int mask_rows, hipStream_t s) {
+  MTGV_CHECK(finalized_, ERR_RUNTIME, "detector: finalize() has not been called");
+  if (!count_flops_) {
+    MTGV_CHECK(n > 0 && n <= cfg_.max_batch, ERR_INVALID, "batch %d outside [1, %d]", n, cfg_.max_batch);
+    MTGV_CHECK(frames && n_det && boxes && conf && cls && keep_idx, ERR_INVALID, "null tensor");
+    MTGV_CHECK(mask_logits == nullptr || (mask_rows > 0 && mask_rows <= cfg_.max_det), ERR_INVALID, "mask_rows=%d", mask_rows);
+  }
+  const int S = cfg_.imgsz;
+  const int c64 = chn(256), c128 = chn(512), c256 = chn(1024);
+  auto V = [&](const char* k) -> const View& { return v_.at(k); };
+
+  if (!count_flops_) u8_to_f32_launch(frames, V("x0").p, (long)n * S * S, 3, 4, 1.0f, 0.0f, flip, s);
+  conv(cw_.at("model.0"), V("x0"), V("l0"), 2, ACT_SILU, nullptr, n, s);
+  conv(cw_.at("model.1"), V("l0"), V("l1"), 2, ACT_SILU, nullptr, n, s);
+  c2f(2, V("l1"), V("l2"), n, s);
+  conv(cw_.at("model.3"), V("l2"), V("l3"), 2, ACT_SILU, nullptr, n, s);
+  const View n4 = V("cat14").slice(c128, c64);      // node 4 output lives in concat 14 = [up(12), 4]
+  c2f(4, V("l3"), n4, n, s);
+  conv(cw_.at("model.5"), n4, V("l5"), 2, ACT_SILU, nullptr, n, s);
+  const View n6 = V("cat11").slice(c256, c128);     // concat 11 = [up(9), 6]
+  c2f(6, V("l5"), n6, n, s);
+  conv(cw_.at("model.7"), n6, V("l7"), 2, ACT_SILU, nullptr, n, s);
+  c2f(8, V("l7"), V("l8"), n, s);
+  // SPPF: cv1, three chained 5x5 max pools, cv2 over the concat
+  const View spp = V("sppcat");
+  const int ch = c256 / 2;
+  conv(cw_.at("model.9.cv1"), V("l8"), spp.slice(0, ch), 1, ACT_SILU, nullptr, n, s);
+  if (!count_flops_)
+    for (int i = 0; i < 3; ++i) maxpool5_launch(spp.p, spp.ct, i * ch, spp.p, spp.ct, (i + 1) * ch, n, spp.H, spp.W, ch, s);
+  const View n9 = V("cat20").slice(c128, c256);     // concat 20 = [19, 9]
+  conv(cw_.at("model.9.cv2"), spp, n9, 1, ACT_SILU, nullptr, n, s);
+  // top-down
+  const View cat11 = V("cat11"), cat14 = V("cat14"), cat17 = V("cat17"), cat20 = V("cat20");
+  if (!count_flops_) upsample2x_launch(n9.p, n9.ct, n9.co, cat11.p, cat11.ct, 0, n, n9.H, n9.W, c256, s);
+  const View n12 = cat17.slice(c64, c128);          // concat 17 = [16, 12]
+  c2f(12, cat11, n12, n, s);
+  if (!count_flops_) upsample2x_launch(n12.p, n12.ct, n12.co, cat14.p, cat14.ct, 0, n, n12.H, n12.W, c128, s);
+  c2f(15, cat14, V("p3"), n, s);
+  conv(cw_.at("model.16"), V("p3"), cat17.slice(0, c64), 2, ACT_SILU, nullptr, n, s);
+  c2f(18, cat17, V("p4"), n, s);
+  conv(cw_.at("model.19"), V("p4"), cat20.slice(0, c128), 2, ACT_SILU, nullptr, n, s);
+  c2f(21, cat20, V("p5"), n, s);
+
+  // Segment head
+  const char* feats[3] = {"p3", "p4", "p5"};
+  for (int l = 0; l < 3; ++l) {
+    const View f = V(feats[l]);
+    View t1 = V("t1"), t2 = V("t2");
+    t1.H = t2.H = f.H, t1.W = t2.W = f.W;
+    conv(head_first_[l], f, t1, 1, ACT_SILU, nullptr, n, s);
+    conv(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, ACT_SILU, nullptr, n, s);
+    conv(head_cls2_[l], t1.slice(64, 64), t2.slice(64, 64), 1, ACT_SILU, nullptr, n, s);
+    conv(head_coef2_[l], t1.slice(128, 32), t2.slice(128, 32), 1, ACT_SILU, nullptr, n, s);
+    View rh;
+    rh.p = rawhead_[l], rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
+    conv(head_box3_[l], t2.slice(0, 64), rh.slice(0, 64), 1, ACT_NONE, nullptr, n, s);
+    conv(head_cls3_[l], t2.slice(64, 64), rh.slice(RAW_CLS, cfg_.nc), 1, ACT_NONE, nullptr, n, s);
+    conv(head_coef3_[l], t2.slice(128, 32), rh.slice(RAW_COEF, nm_), 1, ACT_NONE, nullptr, n, s);
+  }
+  // Proto: Conv3 -> ConvTranspose2d(k2,s2) as four scattered 1x1 GEMMs -> Conv3 -> Conv1
+  conv(cw_.at("model.22.proto.cv1"), V("p3"), V("pr1"), 1, ACT_SILU, nullptr, n, s);
+  {
+    const View in = V("pr1"), out = V("pr2");
+    for (int q = 0; q < 4; ++q) {
+      const ConvW& w = proto_up_[q];
+      GemmArgs g;
+      g.A = in.p, g.W = w.w, g.bias = w.b, g.Out = out.p;
+      g.M = n * in.H * in.W, g.N = w.cout, g.K = w.cin;
+      g.H = in.H, g.Wd = in.W, g.c_total = in.ct, g.c_off = 0, g.Cin = w.cin;
+      g.OH = in.H, g.OW = in.W;
+      g.os = 2, g.oy = q >> 1, g.ox = q & 1, g.OH2 = out.H, g.OW2 = out.W;
+      g.ldo = out.ct;
+      if (count_flops_)
+        flops_ += 2.0 * g.M * g.N * g.K;
+      else
+        gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+    }
+  }
+  conv(cw_.at("model.22.proto.cv2"), V("pr2"), V("pr3"), 1, ACT_SILU, nullptr, n, s);
+  conv(cw_.at("model.22.proto.cv3"), V("pr3"), V("protos"), 1, ACT_SILU, nullptr, n, s);
+  if (count_flops_) return;
+
+  const long tot = (long)n * na_;
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rawhead_[0], rawhead_[1], rawhead_[2],
+                     pred_, n, cfg_.nc, nm_, S, na_);
+  HIP_OK(hipGetLastError());
+  nms_launch(pred_, n, cfg_.nc, nm_, na_, cfg_.conf, cfg_.iou, cfg_.max_det, 7680.0f, n_det, boxes, conf, cls, keep_idx, coef_,
+             nms_ws_, nms_ws_bytes_, s);
+  if (mask_logits != nullptr) {
+    // masks = coeffs @ protos^T per image, cropped to the box (process_mask / crop_mask)
+    const View pr = V("protos");
+    const int npx = pr.H * pr.W;
+    GemmArgs g = linear_args(coef_, nm_, pr.p, nullptr, mask_logits, npx, mask_rows, npx, nm_, ACT_NONE);
+    g.batch = n;
+    g.strideA = (long)cfg_.max_det * nm_;
+    g.strideW = (long)npx * nm_;
+    g.strideO = (long)mask_rows * npx;
+    g.m_count = n_det;
+    g.crop_boxes = boxes;
+    g.crop_rows = cfg_.max_det;
+    g.crop_scale = (float)pr.W / (float)S;
+    g.crop_w = pr.W;
+    gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+  }
+  last_n_ = n;
+}
+
+void Detector::raw(int n, float* pred, float* protos, hipStream_t s) {
+  MTGV_CHECK(n > 0 && n <= last_n_, ERR_INVALID, "raw: n=%d but the last forward had %d frames", n, last_n_);
+  if (pred) HIP_OK(hipMemcpyAsync(pred, pred_, (size_t)n * no() * na_ * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (protos) {
+    const View pr = v_.at("protos");
+    const long hw = (long)pr.H * pr.W, total = (long)n * nm_ * hw;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pr.p, protos, nm_, hw, total);
+    HIP_OK(hipGetLastError());
+  }
+}
+
+}  // namespace mtgv
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+using namespace mtgv;
+struct mtgv_detector {
+  Detector impl;
+  explicit mtgv_detector(const mtgv_detector_cfg& c) : impl(c) {}
+};
+
+extern "C" {
+MTGV_API int mtgv_detector_create(const mtgv_detector_cfg* cfg, mtgv_detector** out) {
+  return guarded([&] {
+    MTGV_CHECK(cfg != nullptr && out != nullptr, ERR_INVALID, "null argument");
+    *out = new mtgv_detector(*cfg);
+  });
+}
+MTGV_API void mtgv_detector_destroy(mtgv_detector* h) { delete h; }
+MTGV_API int mtgv_detector_set_param(mtgv_detector* h, const char* key, const float* data_host, int64_t numel) {
+  return guarded([&] {
+    MTGV_CHECK(h && key && data_host, ERR_INVALID, "null argument");
+    h->impl.set_param(key, data_host, numel);
+  });
+}
+MTGV_API int mtgv_detector_missing_params(const mtgv_detector* h) { return h ? h->impl.missing() : -1; }
+MTGV_API int mtgv_detector_finalize(mtgv_detector* h) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
+    h->impl.finalize();
+  });
+}
+MTGV_API int mtgv_detector_forward(mtgv_detector* h, const uint8_t* frames_dev, int32_t n, int32_t flip_rgb, int32_t* n_det_dev,
+                                   float* boxes_dev, float* conf_dev, int32_t* cls_dev, int32_t* keep_idx_dev,
+                                   float* mask_logits_dev, int32_t mask_rows, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
+    h->impl.forward(frames_dev, n, flip_rgb, n_det_dev, boxes_dev, conf_dev, cls_dev, keep_idx_dev, mask_logits_dev, mask_rows,
+                    (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_detector_raw(mtgv_detector* h, int32_t n, float* pred_dev, float* protos_dev, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
+    h->impl.raw(n, pred_dev, protos_dev, (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_detector_flops(const mtgv_detector* h, double* flops_per_frame) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr && flops_per_frame != nullptr, ERR_INVALID, "null argument");
+    *flops_per_frame = h->impl.flops_per_frame();
+  });
+}
+}

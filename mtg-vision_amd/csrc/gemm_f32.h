@@ -43,6 +43,17 @@ struct GemmArgs {
   const float* a_scale = nullptr;
   const float* a_shift = nullptr;
 
+  // batched launch (grid.y = batch index z): operands advance by these element strides per z
+  int batch = 1;
+  long strideA = 0, strideW = 0, strideO = 0;
+  const int* m_count = nullptr;       // [batch] valid rows of batch z (rows beyond are neither read nor written)
+  // crop_mask of process_mask: rows are detections, columns mask pixels n = py*crop_w + px;
+  // values outside the row's box (xyxy image pixels * crop_scale, x in [x1,x2), y in [y1,y2)) become 0
+  const float* crop_boxes = nullptr;  // [batch][crop_rows][4]
+  int crop_rows = 0;                  // boxes per batch (>= M)
+  float crop_scale = 0.f;
+  int crop_w = 1;
+
   // match path: instead of storing Out, keep the top-`topk` (score desc, id asc)
   // columns of every row per column tile: cand[m][tile_n][topk]
   float* cand_s = nullptr;

@@ -24,7 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmDev {
   GemmArgs a;
-  FastDiv d_ohw, d_ow, d_cin, d_kwcin, d_hw;
+  FastDiv d_ohw, d_ow, d_cin, d_kwcin, d_hw, d_cw;
   int tiles_m, tiles_n;
   int remap;  // output rows are not simply m
 };
@@ -44,6 +44,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
 
   const GemmArgs& p = g.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int z = blockIdx.y;
+  const float* const Ap = p.A + (long)z * p.strideA;
+  const float* const Wp = p.W + (long)z * p.strideW;
+  float* const Op = p.Out + (long)z * p.strideO;
+  int M_eff = p.M;
+  if (p.m_count != nullptr) {
+    const int mc = p.m_count[z];
+    M_eff = mc < p.M ? mc : p.M;
+  }
 
   // XCD-aware tile order: blocks that share an XCD (equal blockIdx % 8) walk a
   // contiguous run of tiles, n fastest, so an A row-panel is fetched once per L2.
@@ -55,6 +64,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
   }
   const int tile_n = L % g.tiles_n, tile_m = L / g.tiles_n;
   const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+  if (bm0 >= M_eff) return;  // whole tile beyond this batch's rows (uniform per block)
 
   // ---- loader state: each thread stages fixed rows, one float4 column ----
   const int lrow = tid / KQ, lk = (tid % KQ) * 4;
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int m = bm0 + lrow + i * RPP;
-    a_ok[i] = m < p.M;
+    a_ok[i] = m < M_eff;
     const uint32_t mm = a_ok[i] ? (uint32_t)m : 0u;
     if (CONV) {
       const uint32_t img = fdiv(mm, g.d_ohw);
@@ -109,9 +119,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
       if (CONV) {
         const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
         if (a_ok[i] && kok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.Wd)
-          v = *reinterpret_cast<const f32x4*>(p.A + (a_row[i] + (long)ih * p.Wd + iw) * p.c_total + p.c_off + c);
+          v = *reinterpret_cast<const f32x4*>(Ap + (a_row[i] + (long)ih * p.Wd + iw) * p.c_total + p.c_off + c);
       } else {
-        if (a_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(p.A + a_row[i] + k);
+        if (a_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(Ap + a_row[i] + k);
       }
       if (APRO) {
         if (a_ok[i] && kok) {
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(p.W + b_row[i] + k);
+      if (b_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(Wp + b_row[i] + k);
       rb[i] = v;
     }
   };
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
             const int oi = __shfl_xor(bi, mask);
             if (os > bs || (os == bs && oi < bi)) bs = os, bi = oi;
           }
-          if (col == 0 && m < p.M) {
+          if (col == 0 && m < M_eff) {
             const long o = ((long)m * g.tiles_n + tile_n) * p.topk + kk;
             p.cand_s[o] = bs;
             p.cand_i[o] = (bs == -INFINITY) ? -1 : bi;
@@ -240,8 +250,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
       for (int r = 0; r < 16; ++r) {
         const int m = bm0 + wave * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = 0.f;
-        if (m < p.M && nok) {
+        if (m < M_eff && nok) {
           v = apply_act(acc[i][j][r] + bv, p.act);
+          if (p.crop_boxes != nullptr) {
+            const float* bx = p.crop_boxes + ((long)z * p.crop_rows + m) * 4;
+            const uint32_t py = fdiv((uint32_t)n, g.d_cw);
+            const float fx = (float)((uint32_t)n - py * (uint32_t)p.crop_w), fy = (float)py;
+            const bool inside = fx >= __fmul_rn(bx[0], p.crop_scale) && fx < __fmul_rn(bx[2], p.crop_scale) &&
+                                fy >= __fmul_rn(bx[1], p.crop_scale) && fy < __fmul_rn(bx[3], p.crop_scale);
+            if (!inside) v = 0.f;
+          }
           float o = v;
           if (p.res != nullptr) o += p.res[(long)m * p.ldr + n];
           long orow = m;
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
             const uint32_t ow = rem - oh * (uint32_t)p.OW;
             orow = ((long)img * p.OH2 + oh * p.os + p.oy) * p.OW2 + ow * p.os + p.ox;
           }
-          p.Out[orow * p.ldo + p.o_off + n] = o;
+          Op[orow * p.ldo + p.o_off + n] = o;
         }
         acc[i][j][r] = v;
       }
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
   // ---- GRN partial sums of squares, segmented by image, fixed summation order ----
   if (p.grn_part != nullptr) {
     float* red = smem;  // [4][BN]; the K loop ended on a barrier, LDS is free
-    const int m_end = (bm0 + BM < p.M) ? bm0 + BM : p.M;
+    const int m_end = (bm0 + BM < M_eff) ? bm0 + BM : M_eff;
     const int img_first = (int)fdiv((uint32_t)bm0, g.d_hw);
     const int img_last = (int)fdiv((uint32_t)(m_end - 1), g.d_hw);
     for (int s = 0; s <= img_last - img_first; ++s) {
@@ -344,11 +362,11 @@ static void launch_variant(const GemmDev& g, bool conv, bool apro, int grid, hip
     attr_done = true;
   }
   if (apro) {
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, false, true, 0>), dim3(grid), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, false, true, 0>), dim3(grid, g.a.batch), dim3(256), lds, s, g);
   } else if (conv) {
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, true, false, 0>), dim3(grid), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, true, false, 0>), dim3(grid, g.a.batch), dim3(256), lds, s, g);
   } else {
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, false, false, 0>), dim3(grid), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, false, false, 0>), dim3(grid, g.a.batch), dim3(256), lds, s, g);
   }
 }
 
@@ -364,6 +382,7 @@ static void launch_topk(const GemmDev& g, int grid, hipStream_t s) {
 }
 
 void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
+  MTGV_CHECK(a.batch >= 1 && a.batch <= 65535, ERR_INVALID, "gemm: batch=%d", a.batch);
   MTGV_CHECK(a.M > 0 && a.N > 0 && a.K > 0, ERR_INVALID, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   MTGV_CHECK(a.K % 4 == 0 && a.Cin % 4 == 0 && a.c_total % 4 == 0 && a.c_off % 4 == 0, ERR_INVALID,
              "gemm: K=%d Cin=%d c_total=%d c_off=%d must be multiples of 4", a.K, a.Cin, a.c_total, a.c_off);
@@ -384,6 +403,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   g.d_cin = make_fastdiv((uint32_t)a.Cin);
   g.d_kwcin = make_fastdiv((uint32_t)(a.KW * a.Cin));
   g.d_hw = make_fastdiv((uint32_t)(a.hw > 0 ? a.hw : 1));
+  g.d_cw = make_fastdiv((uint32_t)(a.crop_w > 0 ? a.crop_w : 1));
   g.tiles_m = pl.tiles_m;
   g.tiles_n = pl.tiles_n;
   g.remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);

@@ -73,7 +73,7 @@ SIGNATURES = {
     "mtgv_detector_set_param": (C.c_int, [c_vp, C.c_char_p, c_vp, c_i64]),
     "mtgv_detector_missing_params": (C.c_int, [c_vp]),
     "mtgv_detector_finalize": (C.c_int, [c_vp]),
-    "mtgv_detector_forward": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mtgv_detector_forward": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "mtgv_detector_raw": (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     "mtgv_detector_flops": (C.c_int, [c_vp, C.POINTER(C.c_double)]),
     "mtgv_nms": (
@@ -81,7 +81,8 @@ SIGNATURES = {
         [c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp],
     ),
     "mtgv_nms_workspace_bytes": (C.c_size_t, [c_i32, c_i32]),
-    "mtgv_warp_quads": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
+    "mtgv_warp_workspace_bytes": (C.c_size_t, [c_i32]),
+    "mtgv_warp_quads": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, C.c_double, c_vp, c_vp, C.c_size_t, c_vp]),
     "mtgv_op_linear": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "mtgv_op_conv2d": (C.c_int, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 10 + [c_vp]),
     "mtgv_op_layernorm": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),

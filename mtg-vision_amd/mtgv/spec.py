@@ -292,3 +292,130 @@ class DetectorConfig:
     @property
     def no(self) -> int:
         return 4 + self.nc + self.nm
+
+
+# ---- YOLOv8n-seg graph (ultralytics cfg/models/v8/yolov8-seg.yaml, scale "n") ----------
+# (index, kind, args): Conv(cout,k,s) | C2f(cout,n,shortcut) | SPPF(cout) | Upsample | Concat(srcs)
+def yolov8_seg_graph(cfg: DetectorConfig):
+    c, r = cfg.ch, cfg.rep
+    return [
+        (0, "Conv", (c(64), 3, 2)),
+        (1, "Conv", (c(128), 3, 2)),
+        (2, "C2f", (c(128), r(3), True)),
+        (3, "Conv", (c(256), 3, 2)),
+        (4, "C2f", (c(256), r(6), True)),
+        (5, "Conv", (c(512), 3, 2)),
+        (6, "C2f", (c(512), r(6), True)),
+        (7, "Conv", (c(1024), 3, 2)),
+        (8, "C2f", (c(1024), r(3), True)),
+        (9, "SPPF", (c(1024),)),
+        (10, "Upsample", ()),
+        (11, "Concat", (10, 6)),
+        (12, "C2f", (c(512), r(3), False)),
+        (13, "Upsample", ()),
+        (14, "Concat", (13, 4)),
+        (15, "C2f", (c(256), r(3), False)),
+        (16, "Conv", (c(256), 3, 2)),
+        (17, "Concat", (16, 12)),
+        (18, "C2f", (c(512), r(3), False)),
+        (19, "Conv", (c(512), 3, 2)),
+        (20, "Concat", (19, 9)),
+        (21, "C2f", (c(1024), r(3), False)),
+    ]
+
+
+def _conv_bn_keys(prefix: str, cout: int, cin: int, k: int):
+    return OrderedDict(
+        [
+            (f"{prefix}.conv.weight", (cout, cin, k, k)),
+            (f"{prefix}.bn.weight", (cout,)),
+            (f"{prefix}.bn.bias", (cout,)),
+            (f"{prefix}.bn.running_mean", (cout,)),
+            (f"{prefix}.bn.running_var", (cout,)),
+        ]
+    )
+
+
+def detector_param_shapes(cfg: DetectorConfig) -> "OrderedDict[str, tuple]":
+    """ultralytics state_dict keys of YOLOv8n-seg (``num_batches_tracked`` buffers omitted).
+
+    Third-party layout, recalled from ultralytics 8.3.x (pyproject.toml:32 pins ~=8.3.80); it
+    cannot be checked against the package in this environment.
+    """
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+    chans = {-1: 3}
+    prev = 3
+    for idx, kind, a in yolov8_seg_graph(cfg):
+        p = f"model.{idx}"
+        if kind == "Conv":
+            cout, k, _ = a
+            out.update(_conv_bn_keys(p, cout, prev, k))
+            prev = cout
+        elif kind == "C2f":
+            cout, n, _ = a
+            ch = cout // 2
+            out.update(_conv_bn_keys(f"{p}.cv1", 2 * ch, prev, 1))
+            out.update(_conv_bn_keys(f"{p}.cv2", cout, (2 + n) * ch, 1))
+            for j in range(n):
+                out.update(_conv_bn_keys(f"{p}.m.{j}.cv1", ch, ch, 3))
+                out.update(_conv_bn_keys(f"{p}.m.{j}.cv2", ch, ch, 3))
+            prev = cout
+        elif kind == "SPPF":
+            (cout,) = a
+            out.update(_conv_bn_keys(f"{p}.cv1", prev // 2, prev, 1))
+            out.update(_conv_bn_keys(f"{p}.cv2", cout, prev // 2 * 4, 1))
+            prev = cout
+        elif kind == "Concat":
+            prev = sum(chans[s] for s in a)
+        chans[idx] = prev
+    ch = [chans[15], chans[18], chans[21]]
+    p = "model.22"
+    c2 = max(16, ch[0] // 4, cfg.reg_max * 4)
+    c3 = max(ch[0], min(cfg.nc, 100))
+    c4 = max(ch[0] // 4, cfg.nm)
+    for name, cmid, cout in (("cv2", c2, 4 * cfg.reg_max), ("cv3", c3, cfg.nc)):
+        for l, cl in enumerate(ch):
+            out.update(_conv_bn_keys(f"{p}.{name}.{l}.0", cmid, cl, 3))
+            out.update(_conv_bn_keys(f"{p}.{name}.{l}.1", cmid, cmid, 3))
+            out[f"{p}.{name}.{l}.2.weight"] = (cout, cmid, 1, 1)
+            out[f"{p}.{name}.{l}.2.bias"] = (cout,)
+    out[f"{p}.dfl.conv.weight"] = (1, cfg.reg_max, 1, 1)
+    out.update(_conv_bn_keys(f"{p}.proto.cv1", cfg.npr, ch[0], 3))
+    out[f"{p}.proto.upsample.weight"] = (cfg.npr, cfg.npr, 2, 2)  # ConvTranspose2d: (in, out, kh, kw)
+    out[f"{p}.proto.upsample.bias"] = (cfg.npr,)
+    out.update(_conv_bn_keys(f"{p}.proto.cv2", cfg.npr, cfg.npr, 3))
+    out.update(_conv_bn_keys(f"{p}.proto.cv3", cfg.nm, cfg.npr, 1))
+    for l, cl in enumerate(ch):
+        out.update(_conv_bn_keys(f"{p}.cv4.{l}.0", c4, cl, 3))
+        out.update(_conv_bn_keys(f"{p}.cv4.{l}.1", c4, c4, 3))
+        out[f"{p}.cv4.{l}.2.weight"] = (cfg.nm, c4, 1, 1)
+        out[f"{p}.cv4.{l}.2.bias"] = (cfg.nm,)
+    return out
+
+
+def random_detector_state(cfg: DetectorConfig, seed: int, cls_bias: float = -2.1) -> Dict[str, np.ndarray]:
+    """Seeded synthetic detector weights (no trained weights exist offline).
+
+    Conv weights are fan-in scaled so activations stay O(1) through the SiLU stack; the
+    class-logit bias is shifted by `cls_bias` so that only a few hundred of the 8400
+    anchors pass conf 0.25 on random frames."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = OrderedDict()
+    for key, shape in detector_param_shapes(cfg).items():
+        leaf = key.rsplit(".", 1)[-1]
+        if key.endswith("dfl.conv.weight"):
+            a = np.arange(cfg.reg_max, dtype=np.float64).reshape(shape)
+        elif key.endswith("proto.upsample.weight"):
+            a = rng.standard_normal(shape) * (1.6 / np.sqrt(shape[0]))
+        elif leaf == "weight" and len(shape) == 4:
+            a = rng.standard_normal(shape) * (1.6 / np.sqrt(_fan_in(shape)))
+        elif leaf == "weight":  # bn scale
+            a = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif leaf == "running_var":
+            a = 1.0 + 0.2 * np.abs(rng.standard_normal(shape))
+        else:  # biases, bn shift, running_mean
+            a = 0.1 * rng.standard_normal(shape)
+            if ".cv3." in key and key.endswith("2.bias"):
+                a = a + cls_bias
+        sd[key] = np.ascontiguousarray(a, dtype=np.float32)
+    return sd
