@@ -259,6 +259,7 @@ void Detector::finalize() {
     const std::string suf = ".conv.weight";
     if (k.size() > suf.size() && k.compare(k.size() - suf.size(), suf.size(), suf) == 0) {
       const std::string pre = k.substr(0, k.size() - suf.size());
+      if (raw_.find(pre + ".bn.weight") == raw_.end()) continue;  // dfl.conv has no BatchNorm
       cw_[pre] = fold(pre, pre == "model.0" ? 4 : 0);
     }
   }

@@ -108,16 +108,28 @@ def test_detect_matches_oracle(det_setup):
         np.testing.assert_array_equal(o["keep_idx"][i, :k], same_in["keep_idx"])
         np.testing.assert_array_equal(o["cls"][i, :k], same_in["cls"])
         np.testing.assert_array_equal(o["boxes"][i, :k], same_in["boxes"])
-        # (2) end to end the kept set is the CPU oracle's
+        # (2) end to end (HIP forward + HIP NMS vs CPU forward + CPU NMS): the two forwards differ by
+        # fp32 summation order (~1e-6), so a keep/suppress decision that sits within rounding of the
+        # conf or IoU threshold may flip; everything else must be identical, in the same order.
         ref = ref_dets[i]
-        assert k == len(ref["keep_idx"]) and k > 10
-        np.testing.assert_array_equal(o["keep_idx"][i, :k], ref["keep_idx"])
-        np.testing.assert_array_equal(o["cls"][i, :k], ref["cls"])
-        assert np.abs(o["boxes"][i, :k] - ref["boxes"]).max() < 640 * 1e-4
-        assert np.abs(o["conf"][i, :k] - ref["conf"]).max() < 1e-4
+        got_idx, ref_idx = o["keep_idx"][i, :k], ref["keep_idx"]
+        common = np.intersect1d(got_idx, ref_idx)
+        flips = max(k, len(ref_idx)) - len(common)
+        print(f"frame {i}: kept {k} (oracle {len(ref_idx)}), threshold flips {flips}")
+        assert k > 10 and flips <= max(3, k // 50)
+        gi = {a: j for j, a in enumerate(got_idx)}
+        ri = {a: j for j, a in enumerate(ref_idx)}
+        gsel = np.asarray([gi[a] for a in common]); rsel = np.asarray([ri[a] for a in common])
+        # order: both score-descending; anchors whose scores differ by less than the forward noise may swap
+        assert (np.diff(o["conf"][i, :k]) <= 0).all()
+        moved = np.abs(gsel - rsel)
+        assert moved.max() <= 2 + flips
+        np.testing.assert_array_equal(o["cls"][i, :k][gsel], ref["cls"][rsel])
+        assert np.abs(o["boxes"][i, :k][gsel] - ref["boxes"][rsel]).max() < 640 * 1e-4
+        assert np.abs(o["conf"][i, :k][gsel] - ref["conf"][rsel]).max() < 1e-4
         # (3) mask logits: coeff @ protos cropped to the box
         ml = o["mask_logits"][i, :k]
-        assert np.abs(ml - ref["mask_logits"]).max() < 1e-4
+        assert np.abs(ml[gsel] - ref["mask_logits"][rsel]).max() < 1e-4
         same = D.mask_logits(pred[i], protos[i], same_in, cfg.nc)
         assert np.abs(ml - same).max() < 2e-5
         assert (ml != 0).any()
