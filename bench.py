@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cards/sec end to end (detect + crop + embed + top-1 over a 100k x 768 bank).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one batch of synthetic frames resident in HBM:
+per GPU 32 frames (640x640x3 uint8) -> YOLOv8n-seg detect + NMS + mask logits -> the 8 best boxes per
+frame de-warped to 192x128 crops -> ConvNeXt-V2 (AE-tiny, z=768) embeddings -> cosine top-1 over the
+bank.  Weak scaling: per-GPU frames are fixed, the bank is sharded by rows over the ranks and the
+per-shard top-k are all-gathered over RCCL/xGMI and merged.  Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "mtg-vision_amd")]
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--cards", type=int, default=8, help="cards per frame (K)")
+    ap.add_argument("--encoder", default="cnvnxt2ae_tiny", help="cnvnxt2ae_tiny | cnvnxt2ae_nano | ...")
+    ap.add_argument("--bank", type=int, default=100_000)
+    ap.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run (see docstring)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the recognition path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mtgv import dist as mdist
+    from mtgv import native, spec
+    from mtgv.detector import Detector
+    from mtgv.encoder import Encoder
+    from mtgv.matcher import Matcher, merge_topk
+    from mtgv.pipeline import Pipeline
+
+    F, K = a.frames, a.cards
+    det_cfg = spec.DetectorConfig()
+    enc_cfg = spec.encoder_config(a.encoder, (192, 128), "conv+linear")
+    det_sd = spec.random_detector_state(det_cfg, 3)
+    enc_sd = spec.random_encoder_state(enc_cfg, 1)
+    detector = Detector(det_cfg, det_sd, max_batch=F)
+    encoder = Encoder(enc_cfg, enc_sd, max_batch=F * K)
+
+    # bank: rng(2) standard normal, generated in row blocks so that every rank can build just its shard
+    sharded = world > 1 and a.bank_mode == "sharded"
+    lo, hi = mdist.shard_rows(a.bank, rank, world) if sharded else (0, a.bank)
+    matcher = Matcher(768, capacity=hi - lo, id_base=lo)
+    blk = 12_500
+    for b0 in range(0, a.bank, blk):
+        b1 = min(a.bank, b0 + blk)
+        if b1 <= lo or b0 >= hi:
+            continue
+        rows = np.random.default_rng([2, b0 // blk]).standard_normal((b1 - b0, 768), dtype=np.float32)
+        matcher.add(rows[max(lo, b0) - b0 : min(hi, b1) - b0])
+    assert len(matcher) == hi - lo
+
+    if sharded:
+        match_fn = lambda z, k: mdist.sharded_topk(z, k, matcher.match, merge_topk)  # noqa: E731
+    else:
+        match_fn = None
+    pipe = Pipeline(detector, encoder, matcher, K, 1, match_fn)
+
+    g = torch.Generator(device=dev).manual_seed(4 + rank)
+    frames = torch.randint(0, 256, (F, 640, 640, 3), generator=g, device=dev, dtype=torch.uint8)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = pipe.run(frames)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = pipe.run(frames)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    cards = world * F * K * a.steps
+    value = cards / dt
+
+    res = {
+        "metric": "cards/sec end-to-end (detect+embed+top-1 over 100k bank), 640x640",
+        "value": round(value, 1),
+        "unit": "cards/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"full pipeline per GPU: {F} frames 640x640x3 u8 -> YOLOv8n-seg(nc=3) detect+NMS+masks -> {K} cards/frame "
+            f"-> 192x128 crops -> ConvNeXt-V2 {a.encoder} (z=768) -> cosine top-1 over {a.bank}x768 bank",
+            "frames_per_gpu": F,
+            "cards_per_frame": K,
+            "bank": [a.bank, 768],
+            "bank_layout": ("row-sharded %d-way + RCCL all-gather of per-shard top-1" % world) if sharded else "replicated",
+            "weights": "random-init (seeded), no trained weights offline",
+        },
+    }
+
+    if rank == 0:
+        L = native.lib()
+        import ctypes as C
+
+        gflops_enc, dw_enc = encoder.flops_per_image()
+        det_flops = detector.flops_per_frame()
+        res["config"]["algorithmic_gflop_per_card"] = round((gflops_enc + dw_enc + det_flops / K + 2 * a.bank * 768) / 1e9, 3)
+        if not a.no_roofline:
+            # dominant kernel = gemm_f32_kernel (every conv / linear / bank GEMM of the path): HIP events around
+            # each of its launches, on the stream they run on, over two more passes of the same step
+            native.check(L.mtgv_profile_gemm(1))
+            nprof = 2
+            for _ in range(nprof):
+                pipe.run(frames)
+            torch.cuda.synchronize()
+            ms, fl, nl = C.c_double(0), C.c_double(0), C.c_int64(0)
+            native.check(L.mtgv_profile_gemm_read(C.byref(ms), C.byref(fl), C.byref(nl)))
+            native.check(L.mtgv_profile_gemm(0))
+            ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    traffic = json.load(open(tfile)).get("hbm_bytes_per_step")
+                except Exception:
+                    traffic = None
+            res["roofline"] = {
+                "bound": "mfma",
+                "kernel": "gemm_f32_kernel (f32-input MFMA implicit GEMM; all launches of one step)",
+                "achieved": round(ach, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": traffic,
+                "launches_per_step": int(nl.value // nprof),
+                "gemm_ms_per_step": round(ms.value / nprof, 3),
+                "algorithmic_gflop_per_step": round(fl.value / nprof / 1e9, 2),
+            }
+        if world == 1 and not a.no_cpu_baseline:
+            # bounded CPU sample of the same workload on the host cores: the oracle pipeline
+            from oracle import pipeline_ref
+
+            nthreads = os.cpu_count() or 1
+            torch.set_num_threads(nthreads)
+            cf = min(a.cpu_frames, F)
+            bank_cpu = matcher.rows(0, len(matcher))
+            fr = frames[:cf].cpu().numpy()
+            pipeline_ref.run(det_sd, det_cfg, enc_sd, enc_cfg, bank_cpu[:1000], fr[:1], K)  # warm the thread pool
+            t0 = time.perf_counter()
+            pipeline_ref.run(det_sd, det_cfg, enc_sd, enc_cfg, bank_cpu, fr, K)
+            cdt = time.perf_counter() - t0
+            res["cpu_baseline"] = {
+                "value": round(cf * K / cdt, 2),
+                "unit": "cards/s",
+                "cores": nthreads,
+                "kind": "port",
+                "sample": f"{cf} frames x {K} cards of the same synthetic workload through oracle/pipeline_ref.py "
+                f"(PyTorch CPU fp32, {nthreads} threads), {cdt:.1f} s",
+            }
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

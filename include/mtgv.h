@@ -40,6 +40,12 @@ MTGV_API int mtgv_version(void);
 /* number of HIP devices visible; does not initialise a device context */
 MTGV_API int mtgv_device_count(void);
 
+/* Measurement aid: when enabled, every launch of the f32-MFMA GEMM kernel is bracketed by HIP
+ * events on its own stream.  _read waits for them and returns the summed kernel time (ms), the
+ * summed algorithmic FLOPs (2*M*N*K of the unpadded problems) and the launch count since enable. */
+MTGV_API int mtgv_profile_gemm(int32_t enable);
+MTGV_API int mtgv_profile_gemm_read(double* total_ms, double* total_flops, int64_t* launches);
+
 /* ------------------------------------------------------------------------- */
 /* Encoder: ConvNeXt-V2 embedding forward.                                    */
 /* Replaces CoreMlEncoder.predict (mtgvision/encoder_export.py:85-110),       */
@@ -150,6 +156,10 @@ MTGV_API int mtgv_detector_forward(mtgv_detector* h, const uint8_t* frames_dev, 
 /* raw head outputs of the last forward: pred (n, 4+nc+32, 8400) and protos (n, 32, 160, 160) */
 MTGV_API int mtgv_detector_raw(mtgv_detector* h, int32_t n, float* pred_dev, float* protos_dev, void* stream);
 MTGV_API int mtgv_detector_flops(const mtgv_detector* h, double* flops_per_frame);
+/* process_mask tail: bilinear x`scale` upsample (align_corners=False) of (n, mh, mw) logits, then > 0
+ * -> (n, mh*scale, mw*scale) uint8 {0,1} */
+MTGV_API int mtgv_mask_binarize(const float* logits_dev, int32_t n, int32_t mh, int32_t mw, int32_t scale, uint8_t* out_dev,
+                                void* stream);
 
 /* NMS alone on decoded predictions pred (n, 4+nc+nm, na) [xywh, class scores, coeffs] */
 MTGV_API int mtgv_nms(const float* pred_dev, int32_t n, int32_t nc, int32_t nm, int32_t na, float conf, float iou,

@@ -31,6 +31,18 @@ MTGV_API int mtgv_device_count(void) {
   return n;
 }
 
+// ---- GEMM launch profiler ----
+MTGV_API int mtgv_profile_gemm(int32_t enable) {
+  return guarded([&] { gemm_profile_enable(enable != 0); });
+}
+MTGV_API int mtgv_profile_gemm_read(double* total_ms, double* total_flops, int64_t* launches) {
+  return guarded([&] {
+    long l = 0;
+    gemm_profile_read(total_ms, total_flops, &l);
+    if (launches) *launches = l;
+  });
+}
+
 // ---- encoder ----
 MTGV_API int mtgv_encoder_create(const mtgv_encoder_cfg* cfg, mtgv_encoder** out) {
   return guarded([&] {

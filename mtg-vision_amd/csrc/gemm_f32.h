@@ -73,6 +73,10 @@ int gemm_grn_segmax(const GemmPlan& p, int hw);
 size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw);
 void gemm_launch(const GemmArgs& a, const GemmPlan& p, hipStream_t s);
 
+// launch profiler for the roofline measurement (off by default; adds two event records per launch)
+void gemm_profile_enable(bool on);
+void gemm_profile_read(double* ms, double* flops, long* launches);
+
 // sum the partials of one GEMM into the GRN apply table
 //   scale[img][n] = gamma[n] * Gx / (mean_n Gx + 1e-6) + 1,  Gx = sqrt(sum x^2)
 void grn_finalize_launch(const float* part, const GemmPlan& p, int n_img, int hw, int N, const float* gamma,

@@ -16,6 +16,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 namespace mtgv {
 
@@ -315,6 +316,55 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
 // host side
 // ---------------------------------------------------------------------------
 
+// Optional launch profiler (bench.py roofline leg): HIP events bracket every GEMM launch on the
+// stream it is launched on; algorithmic FLOPs = 2*M*N*K of the real (unpadded) problem.
+namespace {
+struct GemmProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+  double flops = 0;
+  long launches = 0;
+} g_prof;
+}  // namespace
+
+void gemm_profile_enable(bool on) {
+  g_prof.on = on;
+  g_prof.used = 0;
+  g_prof.flops = 0;
+  g_prof.launches = 0;
+}
+
+void gemm_profile_read(double* ms, double* flops, long* launches) {
+  double total = 0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    HIP_OK(hipEventSynchronize(g_prof.ev[i + 1]));
+    float t = 0.f;
+    HIP_OK(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+    total += t;
+  }
+  if (ms) *ms = total;
+  if (flops) *flops = g_prof.flops;
+  if (launches) *launches = g_prof.launches;
+}
+
+static void prof_begin(const GemmArgs& a, hipStream_t s) {
+  if (!g_prof.on) return;
+  while (g_prof.ev.size() < g_prof.used + 2) {
+    hipEvent_t e;
+    HIP_OK(hipEventCreate(&e));
+    g_prof.ev.push_back(e);
+  }
+  HIP_OK(hipEventRecord(g_prof.ev[g_prof.used], s));
+  g_prof.flops += 2.0 * (double)a.M * a.N * a.K * a.batch;
+  g_prof.launches += 1;
+}
+static void prof_end(hipStream_t s) {
+  if (!g_prof.on) return;
+  HIP_OK(hipEventRecord(g_prof.ev[g_prof.used + 1], s));
+  g_prof.used += 2;
+}
+
 GemmPlan gemm_plan(int M, int N, int K) {
   GemmPlan pl;
   if (const char* e = getenv("MTGV_GEMM_TILE")) {
@@ -409,11 +459,13 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   g.remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
   const int grid = pl.tiles_m * pl.tiles_n;
 
+  prof_begin(a, s);
   if (a.topk > 0) {
     MTGV_CHECK(pl.tm == 1 && pl.tn == 4 && pl.bk == 32 && !conv && !apro, ERR_INVALID, "gemm: top-k epilogue needs the 128x128x32 tile");
     MTGV_CHECK(a.cand_s != nullptr && a.cand_i != nullptr && a.topk <= 128, ERR_INVALID, "gemm: bad top-k arguments");
     launch_topk(g, grid, s);
     HIP_OK(hipGetLastError());
+    prof_end(s);
     return;
   }
 
@@ -421,6 +473,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   if (pl.tm == TM_ && pl.tn == TN_ && pl.bk == BK_) {              \
     launch_variant<TM_, TN_, BK_>(g, conv, apro, grid, s);         \
     HIP_OK(hipGetLastError());                                     \
+    prof_end(s);                                                   \
     return;                                                        \
   }
   MTGV_CASE(1, 1, 16) MTGV_CASE(1, 2, 16) MTGV_CASE(1, 3, 16) MTGV_CASE(1, 4, 16) MTGV_CASE(1, 5, 16)

@@ -87,14 +87,15 @@ void Bank::get_rows(int64_t row, int64_t n, float* out_host) const {
 }
 
 void Bank::topk(const float* q, int b, int k, int64_t id_base, int64_t* ids, float* scores, hipStream_t s) {
-  MTGV_CHECK(b > 0 && k > 0 && k <= 128, ERR_INVALID, "bank: b=%d k=%d (k must be in [1,128])", b, k);
+  MTGV_CHECK(b > 0 && k > 0 && k <= 65536, ERR_INVALID, "bank: b=%d k=%d (k must be in [1,65536])", b, k);
   MTGV_CHECK(q != nullptr && ids != nullptr && scores != nullptr, ERR_INVALID, "bank: null tensor");
   MTGV_CHECK(size_ > 0, ERR_RUNTIME, "bank is empty");
   GemmPlan pl;
   pl.tm = 1, pl.tn = 4, pl.bk = 32;
   pl.tiles_m = ceil_div(b, pl.bm());
   pl.tiles_n = ceil_div((int)size_, pl.bn());
-  const size_t ncand = (size_t)pl.tiles_n * k;
+  const int kt = k < pl.bn() ? k : pl.bn();  // a 128-column tile cannot contribute more than 128 candidates
+  const size_t ncand = (size_t)pl.tiles_n * kt;
   qn_.ensure((size_t)b * dim_);
   cand_s_.ensure((size_t)b * ncand);
   cand_i_.ensure((size_t)b * ncand);
@@ -102,7 +103,7 @@ void Bank::topk(const float* q, int b, int k, int64_t id_base, int64_t* ids, flo
   GemmArgs g = linear_args(qn_.p, dim_, vecs_.p, nullptr, nullptr, 0, b, (int)size_, dim_, ACT_NONE);
   g.cand_s = cand_s_.p;
   g.cand_i = reinterpret_cast<int*>(cand_i_.p);
-  g.topk = k;
+  g.topk = kt;
   gemm_launch(g, pl, s);
   hipLaunchKernelGGL((topk_merge_kernel<int>), dim3(b), dim3(256), 0, s, cand_s_.p, (const int*)cand_i_.p, (int)ncand, k,
                      (long)id_base, (long*)ids, scores);

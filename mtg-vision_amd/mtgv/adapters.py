@@ -1,0 +1,348 @@
+"""Drop-in classes with the reference's names, constructor defaults and methods, so that
+`server.py` / `od_cam.py` / `qdrant_populate.py` / `encoder_validate.py` keep working when their three
+imports point here:
+
+    from mtgvision.encoder_export import CoreMlEncoder        -> mtgv.adapters.CoreMlEncoder
+    from mtgvision.od_export import CardSegmenter             -> mtgv.adapters.CardSegmenter
+    from mtgvision.qdrant import VectorStoreQdrant, QdrantPoint -> mtgv.adapters.VectorStoreQdrant, QdrantPoint
+
+Everything numeric goes to the GPU library; these classes only translate types.
+"""
+
+from __future__ import annotations
+
+from copy import deepcopy
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import spec
+from .crop import warp_quads
+from .detector import Detector, binarize_masks, letterbox
+from .encoder import Encoder
+from .matcher import Matcher
+
+
+# ---------------------------------------------------------------------------
+# encoder: mtgvision/encoder_export.py:85-110
+# ---------------------------------------------------------------------------
+class CoreMlEncoder:
+    """`CoreMlEncoder(model_path).predict(rgb_im) -> (768,)`.
+
+    model_path: a Lightning `.ckpt` / a torch-saved state_dict (keys `model.encoder.*` or encoder
+    keys), loaded with `weights_only=True`.  The reference's default (an absolute macOS path to a
+    `.mlpackage`, encoder_export.py:23-27) has no meaning here; pass `encoder=` to wrap a ready
+    `mtgv.Encoder`, or `state_dict=`."""
+
+    def __init__(self, model_path: Optional[Path] = None, *, model_name: str = "cnvnxt2ae_nano", head_type: str = "conv+linear",
+                 x_size_hw=(192, 128), state_dict=None, encoder: Optional[Encoder] = None, max_batch: int = 64):
+        if encoder is not None:
+            self.model = encoder
+        elif state_dict is not None:
+            self.model = Encoder(spec.encoder_config(model_name, x_size_hw, head_type), state_dict, max_batch=max_batch)
+        else:
+            if model_path is None:
+                raise FileNotFoundError("CoreMlEncoder: no model_path given (the reference's hard-coded default path does not exist here)")
+            self.model = Encoder.from_checkpoint(model_path, model_name, x_size_hw, head_type, max_batch=max_batch)
+
+    def predict(self, rgb_im: np.ndarray):
+        return self.model.predict(rgb_im)  # asserts ndim == 3, last dim 3; returns z[0] of a (1, z) result
+
+    @property
+    def input_hwc(self) -> tuple[int, int, int]:
+        return self.model.input_hwc
+
+    def ran_forward(self):
+        return self.predict(np.random.rand(*self.input_hwc))
+
+
+# ---------------------------------------------------------------------------
+# detector: mtgvision/od_export.py:18-160
+# ---------------------------------------------------------------------------
+def _largest_contour(mask: np.ndarray) -> np.ndarray:
+    """Outer boundary (x, y) of the largest 8-connected blob of a binary mask, Moore tracing.
+
+    Stands in for ultralytics' `masks.xy` (cv2.findContours RETR_EXTERNAL / CHAIN_APPROX_SIMPLE, largest
+    contour).  cv2 is absent: parity unpinned; "next" row of SURVEY.md section 8f."""
+    m = np.pad(mask.astype(bool), 1)
+    if not m.any():
+        return np.zeros((0, 2), np.float32)
+    # label by flood fill over rows (scipy is importable but keep this dependency-free and simple)
+    from scipy import ndimage
+
+    lab, n = ndimage.label(m, structure=np.ones((3, 3), int))
+    if n > 1:
+        sizes = ndimage.sum(m, lab, index=np.arange(1, n + 1))
+        m = lab == (1 + int(np.argmax(sizes)))
+    ys, xs = np.nonzero(m)
+    start = (int(ys[0]), int(xs[ys == ys[0]].min()))
+    nbrs = [(0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1)]  # clockwise from west
+    pts = [start]
+    cur, back = start, 0
+    for _ in range(4 * m.size):
+        found = False
+        for i in range(8):
+            d = (back + i) % 8
+            ny, nx = cur[0] + nbrs[d][0], cur[1] + nbrs[d][1]
+            if m[ny, nx]:
+                back = (d + 5) % 8  # resume the scan just after the pixel we came from
+                cur = (ny, nx)
+                found = True
+                break
+        if not found or cur == start:
+            break
+        pts.append(cur)
+    p = np.asarray(pts, np.float32)[:, ::-1] - 1.0  # (x, y), undo the padding
+    return p
+
+
+def _min_area_rect(points: np.ndarray) -> np.ndarray:
+    """4 corners of the minimum-area rectangle around `points` (rotating calipers over the convex hull)."""
+    from scipy.spatial import ConvexHull
+
+    pts = np.unique(points.astype(np.float64), axis=0)
+    if len(pts) < 3:
+        x1, y1 = pts.min(0)
+        x2, y2 = pts.max(0)
+        return np.asarray([[x1, y1], [x2, y1], [x2, y2], [x1, y2]])
+    try:
+        hull = pts[ConvexHull(pts).vertices]
+    except Exception:
+        x1, y1 = pts.min(0)
+        x2, y2 = pts.max(0)
+        return np.asarray([[x1, y1], [x2, y1], [x2, y2], [x1, y2]])
+    best = None
+    for i in range(len(hull)):
+        e = hull[(i + 1) % len(hull)] - hull[i]
+        n = np.linalg.norm(e)
+        if n == 0:
+            continue
+        ux = e / n
+        uy = np.asarray([-ux[1], ux[0]])
+        a, b = hull @ ux, hull @ uy
+        area = (a.max() - a.min()) * (b.max() - b.min())
+        if best is None or area < best[0]:
+            best = (area, ux, uy, a.min(), a.max(), b.min(), b.max())
+    _, ux, uy, a0, a1, b0, b1 = best
+    return np.asarray([ux * a0 + uy * b0, ux * a1 + uy * b0, ux * a1 + uy * b1, ux * a0 + uy * b1])
+
+
+@dataclass
+class InstanceSeg:
+    points: np.ndarray
+    label: int
+    conf: float
+
+    # private
+    _xyxyxyxy: np.ndarray = None
+    _points_closed: np.ndarray = None
+    _dir_vec: np.ndarray = None
+
+    @property
+    def scores(self) -> np.ndarray:
+        return np.full_like(self.points[:, 0], self.conf)
+
+    @property
+    def center(self) -> np.ndarray:
+        return np.mean(self.xyxyxyxy, axis=0)
+
+    @property
+    def points_closed(self) -> np.ndarray:
+        self._orient()
+        return self._points_closed
+
+    @property
+    def xyxyxyxy(self) -> np.ndarray:
+        self._orient()
+        return self._xyxyxyxy
+
+    @property
+    def dir_vec(self) -> np.ndarray:
+        self._orient()
+        return self._dir_vec
+
+    def _orient(self, mode="u_shape") -> None:
+        """od_export.py:52-93 closes the U-shaped mask with shapely buffer(+/-), takes 4 corners with
+        cv2.approxPolyN and rolls them so that corner 0 is the card's top-left.  shapely / cv2 are absent;
+        this is the build's own statement of the same steps (convex hull as the closed shape, minimum-area
+        rectangle as the quad, centroid difference as the top->bottom direction): SURVEY.md section 8f rank 1."""
+        if self._xyxyxyxy is not None:
+            return
+        assert mode == "u_shape", "Only u_shape dataset mode is supported"
+        pts = np.asarray(self.points, np.float64)
+        box = _min_area_rect(pts)
+        from scipy.spatial import ConvexHull
+
+        try:
+            hull = pts[ConvexHull(pts).vertices]
+        except Exception:
+            hull = box
+        # orig centroid - closed centroid (od_export.py:69-71): the card's bottom is missing from the mask,
+        # so this vector points at the card's top edge
+        v = pts.mean(0) - hull.mean(0)
+        nv = np.linalg.norm(v)
+        v = v / nv if nv > 0 else np.asarray([0.0, -1.0])
+        # the edge the ray centre + t*v crosses becomes edge (0,1) = top of the de-warped card (od_export.py:77-88)
+        c = box.mean(0)
+        idx = 0
+        best = -np.inf
+        for i in range(4):
+            mid = (box[i] + box[(i + 1) % 4]) / 2 - c
+            d = float(mid @ v)
+            if d > best:
+                best, idx = d, i
+        box = np.roll(box, -idx, axis=0)
+        # corners must run tl, tr, br, bl (clockwise in image coordinates, y down)
+        e0, e1 = box[1] - box[0], box[2] - box[1]
+        if e0[0] * e1[1] - e0[1] * e1[0] < 0:
+            box = np.asarray([box[1], box[0], box[3], box[2]])
+        self._xyxyxyxy = box.astype(int)
+        self._points_closed = hull.astype(int)
+        self._dir_vec = v
+
+    def extract_dewarped(self, frame: np.ndarray, out_size_hw: tuple[int, int] = (192, 128), expand_ratio: float = 0.05) -> np.ndarray:
+        """od_export.py:95-111 - perspective crop on the GPU (warp.hip)."""
+        f = torch.from_numpy(np.ascontiguousarray(frame))[None].cuda()
+        q = torch.from_numpy(np.asarray(self.xyxyxyxy).astype(np.float32))[None]
+        out = warp_quads(f, q, torch.zeros(1, dtype=torch.int32), out_size_hw, expand_ratio)
+        return out[0].cpu().numpy()
+
+    def debug_draw_on(self, frame: np.ndarray, color=(128, 128, 128), id: str = None):
+        raise NotImplementedError("debug drawing needs cv2; out of scope for the recognition path (SURVEY.md section 2 row 6)")
+
+
+class CardSegmenter:
+    """`CardSegmenter(model_path)(rgb_im) -> list[InstanceSeg]` (od_export.py:141-160).
+
+    model_path: a torch-saved ultralytics state_dict (`model.<i>...` keys), loaded with
+    `weights_only=True`; or pass `detector=` / `state_dict=`.  `.pt` pickles of whole ultralytics
+    models are not loadable without the package (and are never unpickled here)."""
+
+    def __init__(self, model_path: str | Path = None, *, state_dict=None, detector: Optional[Detector] = None, max_batch: int = 1):
+        if detector is not None:
+            self.yolo = detector
+        else:
+            if state_dict is None:
+                if model_path is None:
+                    raise FileNotFoundError("CardSegmenter: no model_path given (the reference's hard-coded default path does not exist here)")
+                state_dict = torch.load(model_path, map_location="cpu", weights_only=True)
+                state_dict = state_dict.get("state_dict", state_dict) if isinstance(state_dict, dict) else state_dict
+            self.yolo = Detector(spec.DetectorConfig(), state_dict, max_batch=max_batch)
+
+    def __call__(self, rgb_im: np.ndarray) -> list[InstanceSeg]:
+        img, ratio, (left, top) = letterbox(rgb_im, self.yolo.cfg.imgsz)
+        det = self.yolo.detect(rgb_im)
+        detections = []
+        if det.mask_logits is not None and det.conf.numel() > 0:
+            masks = binarize_masks(det.mask_logits).cpu().numpy()
+            for m, conf in zip(masks, det.conf.cpu().numpy()):
+                pts = _largest_contour(m)
+                if len(pts) == 0:
+                    continue
+                pts = (pts - np.asarray([left, top], np.float32)) / np.float32(ratio)  # scale_coords back to the frame
+                detections.append(InstanceSeg(points=np.asarray(pts), label=0, conf=np.asarray(conf).tolist()))
+        return detections
+
+
+# ---------------------------------------------------------------------------
+# match: mtgvision/qdrant.py:10-111
+# ---------------------------------------------------------------------------
+@dataclass
+class QdrantPoint:
+    id: str  # UUID
+    vector: list[float] | None = None
+    payload: dict[str, Any] | None = None
+
+
+@dataclass
+class ScoredPoint:
+    """the fields callers read from qdrant's ScoredPoint (server.py:61-70, :192; encoder_validate.py:92)"""
+
+    id: str
+    version: int
+    score: float
+    payload: dict[str, Any] | None = None
+    vector: list[float] | None = None
+
+
+class VectorStoreQdrant:
+    _COLLECTION = "mtg"
+    _VECTOR_SIZE: int = 768
+
+    def __init__(self, location: str = "localhost:6333", *, capacity: int = 131072):
+        # `location` is accepted for signature compatibility; the bank lives in this GPU's HBM
+        self.location = location
+        self._capacity = capacity
+        self._bank = Matcher(self._VECTOR_SIZE, capacity=capacity)
+        self._ids: list[str] = []
+        self._row: dict[str, int] = {}
+        self._payload: dict[str, dict | None] = {}
+
+    def drop_collection(self):
+        self._bank.clear()
+        self._ids, self._row, self._payload = [], {}, {}
+
+    def retrieve(self, ids: Iterable[str], *, with_payload: bool = True, with_vectors: bool = False) -> list[QdrantPoint]:
+        out = []
+        for i in ids:
+            i = str(i)
+            if i not in self._row:
+                continue  # Qdrant returns only the points that exist
+            vec = self._bank.rows(self._row[i], 1)[0].tolist() if with_vectors else None
+            out.append(QdrantPoint(id=i, vector=vec, payload=deepcopy(self._payload.get(i)) if with_payload else None))
+        return out
+
+    def save_points(self, iter_points: Iterable[QdrantPoint]):
+        new_vecs, new_ids = [], []
+        for p in iter_points:
+            v = np.asarray(p.vector, np.float32)
+            assert v.shape == (self._VECTOR_SIZE,), f"{v.shape}"
+            pid = str(p.id)
+            if pid in self._row:  # upsert
+                self._bank.set_row(self._row[pid], v)
+            else:
+                new_vecs.append(v)
+                new_ids.append(pid)
+            self._payload[pid] = deepcopy(p.payload)
+            if len(new_vecs) == 64:  # qdrant.py:73 uploads in batches of 64
+                self._flush(new_vecs, new_ids)
+                new_vecs, new_ids = [], []
+        self._flush(new_vecs, new_ids)
+
+    def _flush(self, vecs, ids):
+        if not vecs:
+            return
+        rows = self._bank.add(np.stack(vecs))
+        for r, pid in zip(rows, ids):
+            self._row[pid] = r
+            self._ids.append(pid)
+
+    def query_nearby(self, vector: list[float], k: int, *, with_payload: bool = True, with_vectors: bool = False,
+                     score_threshold: float = None) -> list[ScoredPoint]:
+        if len(self._bank) == 0 or k <= 0:
+            return []
+        out = []
+        kk = min(int(k), len(self._bank))
+        ids, scores = self._bank.match(np.asarray(vector, np.float32), kk)
+        ids, scores = ids[0].cpu().numpy(), scores[0].cpu().numpy()
+        for i, s in zip(ids, scores):
+            if i < 0:
+                continue
+            if score_threshold is not None and not (s >= score_threshold):
+                continue
+            pid = self._ids[int(i)]
+            out.append(
+                ScoredPoint(
+                    id=pid, version=0, score=float(s),
+                    payload=deepcopy(self._payload.get(pid)) if with_payload else None,
+                    vector=self._bank.rows(int(i), 1)[0].tolist() if with_vectors else None,
+                )
+            )
+        return out
+
+    def update_payload(self, id_: str, payload: dict[str, Any]) -> QdrantPoint:
+        self._payload[str(id_)] = deepcopy(payload)
+        return QdrantPoint(id=id_, vector=None, payload=deepcopy(payload))

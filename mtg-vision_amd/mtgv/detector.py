@@ -178,3 +178,14 @@ def nms(pred: torch.Tensor, nc: int, conf: float = 0.25, iou: float = 0.7, max_d
                        native.ptr(out["conf"]), native.ptr(out["cls"]), native.ptr(out["keep_idx"]), native.ptr(ws), ws.numel() * 4, native.stream())
         )
     return out
+
+
+def binarize_masks(mask_logits: torch.Tensor, scale: int = 4) -> torch.Tensor:
+    """(n, 160, 160) cropped logits -> (n, 640, 640) uint8 {0,1}: bilinear x4 (align_corners=False), > 0."""
+    native.require_gpu()
+    assert mask_logits.is_cuda and mask_logits.dtype == torch.float32 and mask_logits.ndim == 3
+    n, mh, mw = mask_logits.shape
+    out = torch.empty((n, mh * scale, mw * scale), dtype=torch.uint8, device=mask_logits.device)
+    with torch.cuda.device(mask_logits.device):
+        native.check(native.lib().mtgv_mask_binarize(native.ptr(mask_logits.contiguous()), n, mh, mw, scale, native.ptr(out), native.stream()))
+    return out

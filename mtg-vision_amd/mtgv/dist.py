@@ -1,0 +1,65 @@
+"""Multi-GPU layout: one process per GPU, frames data-parallel, bank sharded by rows.
+
+The only exchange step of the path is the match: every query must see every bank row.
+With the bank split by rows over R ranks (rank r holds rows [r*N/R, (r+1)*N/R), global id =
+local row + offset), top-k of the union = merge of per-shard top-k:
+
+    1. all_gather the local query embeddings        (B_local x D fp32 each)
+    2. every rank scores ALL queries against its shard, local top-k (ids already global)
+    3. all_gather the (score, id) candidates         (B_total x k pairs per rank)
+    4. every rank merges the R*k candidates of its OWN queries (score desc, id asc)
+
+Both messages are KB-scale: latency-bound, xGMI bandwidth is irrelevant, so each is a single
+collective (RCCL `all_gather_into_tensor`, backend "nccl" on ROCm).  The local top-k and the merge
+are pluggable so the collective logic is exercised on CPU with gloo (tests/test_dist_cpu.py).
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """contiguous row range [start, stop) of `rank`; remainders go to the first ranks"""
+    base, rem = divmod(n_rows, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_frames(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
+    return shard_rows(n_frames, rank, world)
+
+
+def _all_gather_cat(x: torch.Tensor, group=None) -> torch.Tensor:
+    world = dist.get_world_size(group)
+    out = torch.empty((world, *x.shape), dtype=x.dtype, device=x.device)
+    try:
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):  # backends without the fused form
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x.contiguous(), group=group)
+        out = torch.stack(parts)
+    return out
+
+
+def sharded_topk(q_local: torch.Tensor, k: int, local_topk: Callable, merge: Callable, group=None):
+    """q_local (B_local, D) -> global (ids (B_local, k) int64, scores (B_local, k)) for this rank's queries.
+
+    local_topk(q (B,D), k) -> (ids int64 (B,k) GLOBAL ids, scores (B,k)) over this rank's bank shard.
+    merge(cand_scores (B, R*k), cand_ids (B, R*k), k) -> (ids, scores).
+    Every rank must pass the same B_local."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local_topk(q_local, k)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    b_local = q_local.shape[0]
+    q_all = _all_gather_cat(q_local, group).reshape(world * b_local, -1)
+    ids, scores = local_topk(q_all, k)
+    ids_all = _all_gather_cat(ids.contiguous(), group)  # (R, B_total, k)
+    sc_all = _all_gather_cat(scores.contiguous(), group)
+    mine = slice(rank * b_local, (rank + 1) * b_local)
+    cand_i = ids_all[:, mine].permute(1, 0, 2).reshape(b_local, world * k)
+    cand_s = sc_all[:, mine].permute(1, 0, 2).reshape(b_local, world * k)
+    return merge(cand_s.contiguous(), cand_i.contiguous(), k)

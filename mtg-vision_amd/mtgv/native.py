@@ -51,6 +51,8 @@ SIGNATURES = {
     "mtgv_last_error": (C.c_char_p, []),
     "mtgv_version": (C.c_int, []),
     "mtgv_device_count": (C.c_int, []),
+    "mtgv_profile_gemm": (C.c_int, [c_i32]),
+    "mtgv_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64)]),
     "mtgv_encoder_create": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(c_vp)]),
     "mtgv_encoder_destroy": (None, [c_vp]),
     "mtgv_encoder_set_param": (C.c_int, [c_vp, C.c_char_p, c_vp, c_i64]),
@@ -76,6 +78,7 @@ SIGNATURES = {
     "mtgv_detector_forward": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "mtgv_detector_raw": (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     "mtgv_detector_flops": (C.c_int, [c_vp, C.POINTER(C.c_double)]),
+    "mtgv_mask_binarize": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mtgv_nms": (
         C.c_int,
         [c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp],

@@ -1,0 +1,99 @@
+"""Drop-in classes (reference names / signatures) on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vector_store_contract():
+    """mtgvision/qdrant.py:17-111 semantics: cosine score, top-k sorted desc, threshold, upsert, payloads."""
+    from mtgv.adapters import QdrantPoint, VectorStoreQdrant
+    from oracle import match_ref as M
+
+    rng = np.random.default_rng(5)
+    vecs = rng.standard_normal((300, 768)).astype(np.float32)
+    ids = [f"00000000-0000-0000-0000-{i:012d}" for i in range(300)]
+    db = VectorStoreQdrant(capacity=512)
+    assert db._COLLECTION == "mtg" and db._VECTOR_SIZE == 768
+    db.save_points(QdrantPoint(id=i, vector=v.tolist(), payload={"n": j}) for j, (i, v) in enumerate(zip(ids, vecs)))
+    q = vecs[17] + 0.05 * rng.standard_normal(768).astype(np.float32)
+    res = db.query_nearby(q.tolist(), k=3, with_payload=True)
+    rid, rsc = M.cosine_topk(q[None], vecs, 3)
+    assert [p.id for p in res] == [ids[i] for i in rid[0]]
+    assert res[0].id == ids[17] and res[0].payload == {"n": 17} and res[0].vector is None
+    np.testing.assert_allclose([p.score for p in res], rsc[0], atol=2e-6)
+    thr = float(rsc[0][1]) - 1e-4
+    assert len(db.query_nearby(q, k=3, score_threshold=thr)) == 2
+    big = db.query_nearby(q, k=3000, with_payload=False, score_threshold=0.1)  # qdrant.py:136-142 debug call
+    s64 = M.scores(q[None], vecs)[0]
+    assert len(big) == int((s64 >= 0.1).sum()) and all(p.payload is None for p in big)
+    # retrieve / update_payload / upsert
+    [pt] = db.retrieve([ids[5]], with_payload=True, with_vectors=True)
+    np.testing.assert_allclose(pt.vector, vecs[5] / np.linalg.norm(vecs[5]), atol=1e-6)
+    assert db.retrieve(["missing"]) == []
+    assert db.update_payload(ids[5], {"name": "x"}).payload == {"name": "x"}
+    assert db.retrieve([ids[5]])[0].payload == {"name": "x"}
+    db.save_points([QdrantPoint(id=ids[3], vector=(-vecs[17]).tolist(), payload=None)])
+    assert db.query_nearby(-q, k=1)[0].id == ids[3]
+    db.drop_collection()
+    assert db.query_nearby(q, k=3) == []
+
+
+def test_coreml_encoder_contract():
+    from mtgv import spec
+    from mtgv.adapters import CoreMlEncoder
+    from oracle import encoder_ref as R
+
+    cfg = spec.encoder_config("cnvnxt2ae_nano", (192, 128), "conv+linear")
+    sd = spec.random_encoder_state(cfg, 1)
+    enc = CoreMlEncoder(state_dict=sd, max_batch=2)
+    assert enc.input_hwc == (192, 128, 3)
+    im = np.random.default_rng(3).random((192, 128, 3))  # float64 in [0,1], like ran_forward()
+    z = enc.predict(im)
+    assert z.shape == (768,) and z.dtype == np.float32
+    assert np.abs(z - R.predict_hwc(sd, cfg, im)).max() < 1e-4
+    assert enc.ran_forward().shape == (768,)
+    with pytest.raises(FileNotFoundError):
+        CoreMlEncoder()
+
+
+def test_card_segmenter_and_mask_binarize():
+    from mtgv import spec
+    from mtgv.adapters import CardSegmenter, InstanceSeg
+    from mtgv.detector import Detector, binarize_masks
+    from oracle import detector_ref as D
+
+    cfg = spec.DetectorConfig()
+    sd = spec.random_detector_state(cfg, 3)
+    det = Detector(cfg, sd, max_batch=1)
+    frame = np.random.default_rng(8).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    d = det.detect(frame)
+    mb = binarize_masks(d.mask_logits[:16]).cpu().numpy()
+    ref = D.masks_binary(d.mask_logits[:16].cpu().numpy())
+    assert mb.shape == (16, 640, 640)
+    assert (mb.astype(bool) != ref).mean() < 1e-5  # identical up to bilinear rounding exactly at 0
+    segs = CardSegmenter(detector=det)(frame)
+    assert isinstance(segs, list) and len(segs) > 0 and all(isinstance(s, InstanceSeg) for s in segs)
+    s = segs[0]
+    assert s.label == 0 and 0.25 < s.conf <= 1.0 and s.points.ndim == 2 and s.points.shape[1] == 2
+    assert s.xyxyxyxy.shape == (4, 2) and s.xyxyxyxy.dtype.kind == "i"
+    crop = s.extract_dewarped(frame)
+    assert crop.shape == (192, 128, 3) and crop.dtype == np.uint8
+
+
+def test_orientation_of_u_shape():
+    """a U-shaped polygon (bottom part of the card missing): corner 0/1 must be the card's top edge"""
+    from mtgv.adapters import InstanceSeg
+
+    # card upright at (100..200, 50..250); the mask covers the top 3/4 and two legs -> centroid above the hull's
+    pts = np.array([[100, 50], [200, 50], [200, 250], [180, 250], [180, 200], [120, 200], [120, 250], [100, 250]], float)
+    s = InstanceSeg(points=pts, label=0, conf=0.9)
+    q = s.xyxyxyxy
+    assert sorted(q[:2, 1].tolist()) == [50, 50] and sorted(q[2:, 1].tolist()) == [250, 250]
+    assert q[0, 0] < q[1, 0]  # tl then tr
+    rot = np.array([[0, -1], [1, 0]])  # rotate the card by 90 degrees: top edge now points along -x ... +x
+    s2 = InstanceSeg(points=pts @ rot.T + np.array([400, 0]), label=0, conf=0.9)
+    q2 = s2.xyxyxyxy
+    top_mid = q2[:2].mean(0)
+    assert abs(top_mid[0] - (400 - 50)) < 2  # the top edge is the image of y=50
