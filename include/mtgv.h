@@ -45,6 +45,8 @@ MTGV_API int mtgv_device_count(void);
  * summed algorithmic FLOPs (2*M*N*K of the unpadded problems) and the launch count since enable. */
 MTGV_API int mtgv_profile_gemm(int32_t enable);
 MTGV_API int mtgv_profile_gemm_read(double* total_ms, double* total_flops, int64_t* launches);
+/* write one CSV row per recorded launch (shape, tile, ms, TFLOP/s) */
+MTGV_API int mtgv_profile_gemm_dump(const char* csv_path);
 
 /* ------------------------------------------------------------------------- */
 /* Encoder: ConvNeXt-V2 embedding forward.                                    */

@@ -43,6 +43,13 @@ MTGV_API int mtgv_profile_gemm_read(double* total_ms, double* total_flops, int64
   });
 }
 
+MTGV_API int mtgv_profile_gemm_dump(const char* csv_path) {
+  return guarded([&] {
+    MTGV_CHECK(csv_path != nullptr, ERR_INVALID, "null path");
+    gemm_profile_dump(csv_path);
+  });
+}
+
 // ---- encoder ----
 MTGV_API int mtgv_encoder_create(const mtgv_encoder_cfg* cfg, mtgv_encoder** out) {
   return guarded([&] {
@@ -139,7 +146,7 @@ MTGV_API int mtgv_op_linear(const float* a_dev, const float* w_dev, const float*
     GemmArgs g = linear_args(a_dev, k, w_dev, bias_dev, out_dev, n, m, n, k, act);
     g.res = res_dev;
     g.ldr = n;
-    gemm_launch(g, gemm_plan(m, n, k), (hipStream_t)stream);
+    gemm_launch(g, gemm_plan(m, n, k, act != 0), (hipStream_t)stream);
   });
 }
 MTGV_API int mtgv_op_conv2d(const float* x_dev, const float* w_dev, const float* bias_dev, float* out_dev, int32_t n, int32_t h,
@@ -158,7 +165,7 @@ MTGV_API int mtgv_op_conv2d(const float* x_dev, const float* w_dev, const float*
     g.OH = oh, g.OW = ow, g.OH2 = oh, g.OW2 = ow;
     g.ldo = cout;
     g.act = act;
-    gemm_launch(g, gemm_plan(g.M, g.N, g.K), (hipStream_t)stream);
+    gemm_launch(g, gemm_plan(g.M, g.N, g.K, act != 0), (hipStream_t)stream);
   });
 }
 MTGV_API int mtgv_op_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* out_dev, int64_t rows,

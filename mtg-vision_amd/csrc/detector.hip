@@ -417,7 +417,7 @@ void Detector::conv(const ConvW& w, const View& in, const View& out, int stride,
     flops_ += 2.0 * g.M * g.N * kk;
     return;
   }
-  gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+  gemm_launch(g, gemm_plan(g.M, g.N, g.K, act != ACT_NONE), s);
 }
 
 // C2f: cv1 -> 2 chunks; n bottlenecks (3x3,3x3, +shortcut) each appended; cv2 over the concat

@@ -29,6 +29,8 @@ struct DevBuf {
 struct BlockW {
   float *dw_w49 = nullptr, *dw_b = nullptr, *ln_w = nullptr, *ln_b = nullptr;
   float *w1 = nullptr, *b1 = nullptr, *gamma = nullptr, *beta = nullptr, *w2 = nullptr, *b2 = nullptr;
+  // b2 + W2 . beta: the GRN shift folded into the pwconv2 bias at load time (null -> shift applied in the A prologue)
+  float* b2_folded = nullptr;
 };
 struct BlockWs {
   float *t1 = nullptr, *t2 = nullptr, *hid = nullptr, *part = nullptr, *scale = nullptr;
@@ -54,12 +56,16 @@ struct ParamSlot {
   float* dev = nullptr;
   int64_t numel = 0;
   bool set = false;
+  bool keep_host = false;
+  std::vector<float> host;  // reference-layout copy for load-time folding
 };
 
 class ParamStore {
  public:
   ~ParamStore();
-  float* add(const std::string& key, std::vector<int> shape, Repack r = R_NONE, int perm_p = 0, int perm_c = 0);
+  float* add(const std::string& key, std::vector<int> shape, Repack r = R_NONE, int perm_p = 0, int perm_c = 0,
+             bool keep_host = false);
+  const std::vector<float>& host(const std::string& key) const { return slots_.at(key).host; }
   void set(const std::string& key, const float* host, int64_t numel);
   int missing() const;
   const std::map<std::string, ParamSlot>& slots() const { return slots_; }
@@ -71,7 +77,10 @@ class ParamStore {
 class Encoder {
  public:
   explicit Encoder(const mtgv_encoder_cfg& cfg);
-  void set_param(const char* key, const float* host, int64_t numel) { params_.set(key, host, numel); }
+  void set_param(const char* key, const float* host, int64_t numel) {
+    params_.set(key, host, numel);
+    prepared_ = false;
+  }
   int missing() const { return params_.missing(); }
   void forward(const void* x, int layout, int n, float* z, hipStream_t s);
   void set_capture(bool on);
@@ -95,6 +104,10 @@ class Encoder {
   DevBuf stage_[4];
   bool capture_ = false;
   int last_n_ = 0;
+  bool prepared_ = false;
+  std::vector<std::string> blk_prefix_[4];
+  DevBuf folded_bias_;
+  void prepare();
 };
 
 }  // namespace mtgv

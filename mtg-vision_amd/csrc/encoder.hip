@@ -34,8 +34,9 @@ ParamStore::~ParamStore() {
     if (kv.second.dev) (void)hipFree(kv.second.dev);
 }
 
-float* ParamStore::add(const std::string& key, std::vector<int> shape, Repack r, int perm_p, int perm_c) {
+float* ParamStore::add(const std::string& key, std::vector<int> shape, Repack r, int perm_p, int perm_c, bool keep_host) {
   ParamSlot sl;
+  sl.keep_host = keep_host;
   sl.shape = shape;
   sl.repack = r;
   sl.perm_p = perm_p;
@@ -83,6 +84,7 @@ void ParamStore::set(const std::string& key, const float* host, int64_t numel) {
     src = tmp.data();
   }
   HIP_OK(hipMemcpy(sl.dev, src, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
+  if (sl.keep_host) sl.host.assign(host, host + numel);
   sl.set = true;
 }
 
@@ -115,7 +117,7 @@ BlockWsSize block_ws_size(int n, int h, int w, int c) {
   const size_t M = (size_t)n * h * w;
   z.t = M * c;
   z.hid = M * 4 * c;
-  const GemmPlan pl = gemm_plan((int)M, 4 * c, c);
+  const GemmPlan pl = gemm_plan((int)M, 4 * c, c, true);
   z.part = gemm_grn_part_floats(pl, 4 * c, h * w);
   z.scale = (size_t)n * 4 * c;
   return z;
@@ -128,7 +130,7 @@ void run_block(const float* x, float* out, int n, int h, int w, int c, int act, 
   ln_rows_launch(ws.t1, c, 0, ws.t2, c, 0, bw.ln_w, bw.ln_b, M, c, 1e-6f, s);
 
   GemmArgs g1 = linear_args(ws.t2, c, bw.w1, bw.b1, ws.hid, 4 * c, M, 4 * c, c, act);
-  const GemmPlan p1 = gemm_plan(M, 4 * c, c);
+  const GemmPlan p1 = gemm_plan(M, 4 * c, c, true);
   g1.grn_part = ws.part;
   g1.hw = hw;
   g1.segmax = gemm_grn_segmax(p1, hw);
@@ -141,7 +143,10 @@ void run_block(const float* x, float* out, int n, int h, int w, int c, int act, 
   g2.ldr = c;
   g2.hw = hw;
   g2.a_scale = ws.scale;
-  g2.a_shift = bw.beta;
+  if (bw.b2_folded != nullptr)
+    g2.bias = bw.b2_folded;  // beta already inside the bias
+  else
+    g2.a_shift = bw.beta;
   gemm_launch(g2, gemm_plan(M, c, 4 * c), s);
 }
 
@@ -220,10 +225,11 @@ Encoder::Encoder(const mtgv_encoder_cfg& cfg) : cfg_(cfg) {
       b.w1 = params_.add(blk_key(cfg.kind, s, j, "pwconv1.weight"), {4 * c, c});
       b.b1 = params_.add(blk_key(cfg.kind, s, j, "pwconv1.bias"), {4 * c});
       b.gamma = params_.add(blk_key(cfg.kind, s, j, "grn.gamma"), {1, 1, 1, 4 * c});
-      b.beta = params_.add(blk_key(cfg.kind, s, j, "grn.beta"), {1, 1, 1, 4 * c});
-      b.w2 = params_.add(blk_key(cfg.kind, s, j, "pwconv2.weight"), {c, 4 * c});
-      b.b2 = params_.add(blk_key(cfg.kind, s, j, "pwconv2.bias"), {c});
+      b.beta = params_.add(blk_key(cfg.kind, s, j, "grn.beta"), {1, 1, 1, 4 * c}, R_NONE, 0, 0, true);
+      b.w2 = params_.add(blk_key(cfg.kind, s, j, "pwconv2.weight"), {c, 4 * c}, R_NONE, 0, 0, true);
+      b.b2 = params_.add(blk_key(cfg.kind, s, j, "pwconv2.bias"), {c}, R_NONE, 0, 0, true);
       blocks_[s].push_back(b);
+      blk_prefix_[s].push_back(blk_key(cfg.kind, s, j, ""));
     }
   }
   const int z = cfg.z_size, c3 = d[3];
@@ -283,6 +289,34 @@ Encoder::Encoder(const mtgv_encoder_cfg& cfg) : cfg_(cfg) {
   head_b2_.alloc((size_t)nb * std::max(z, c3) + 16);
 }
 
+// GRN's "+ beta" (convnextv2.py:174) commutes with the following Linear: (h*s + beta) W2^T + b2 =
+// (h*s) W2^T + (W2 beta + b2), so it is folded into the pwconv2 bias once per weight load (float64 dot).
+void Encoder::prepare() {
+  size_t total = 0;
+  for (int s = 0; s < 4; ++s) total += blocks_[s].size() * (size_t)cfg_.dims[s];
+  folded_bias_.ensure(total);
+  std::vector<float> all(total);
+  size_t off = 0;
+  for (int s = 0; s < 4; ++s) {
+    const int c = cfg_.dims[s];
+    for (size_t j = 0; j < blocks_[s].size(); ++j) {
+      const std::string& pre = blk_prefix_[s][j];
+      const auto& w2 = params_.host(pre + "pwconv2.weight");
+      const auto& b2 = params_.host(pre + "pwconv2.bias");
+      const auto& beta = params_.host(pre + "grn.beta");
+      for (int n = 0; n < c; ++n) {
+        double acc = b2[n];
+        for (int k = 0; k < 4 * c; ++k) acc += (double)w2[(size_t)n * 4 * c + k] * (double)beta[k];
+        all[off + n] = (float)acc;
+      }
+      blocks_[s][j].b2_folded = folded_bias_.p + off;
+      off += c;
+    }
+  }
+  HIP_OK(hipMemcpy(folded_bias_.p, all.data(), total * sizeof(float), hipMemcpyHostToDevice));
+  prepared_ = true;
+}
+
 void Encoder::set_capture(bool on) {
   capture_ = on;
   if (on)
@@ -323,6 +357,7 @@ void Encoder::forward(const void* x, int layout, int n, float* z_out, hipStream_
   MTGV_CHECK(params_.missing() == 0, ERR_RUNTIME, "encoder has %d unset parameters", params_.missing());
   MTGV_CHECK(n > 0 && n <= cfg_.max_batch, ERR_INVALID, "batch %d outside [1, %d]", n, cfg_.max_batch);
   MTGV_CHECK(x != nullptr && z_out != nullptr, ERR_INVALID, "null tensor");
+  if (!prepared_) prepare();
   const int H = cfg_.image_h, W = cfg_.image_w;
   const float sc = cfg_.scale_io ? 2.0f : 1.0f, sf = cfg_.scale_io ? -1.0f : 0.0f;
   if (layout == MTGV_IN_NCHW_F32)

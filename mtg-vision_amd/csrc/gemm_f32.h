@@ -68,7 +68,8 @@ struct GemmPlan {
   int bn() const { return 32 * tn; }
 };
 
-GemmPlan gemm_plan(int M, int N, int K);
+// heavy_epilogue: the launch applies an activation (transcendentals per output element)
+GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue = false);
 int gemm_grn_segmax(const GemmPlan& p, int hw);
 size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw);
 void gemm_launch(const GemmArgs& a, const GemmPlan& p, hipStream_t s);
@@ -76,6 +77,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& p, hipStream_t s);
 // launch profiler for the roofline measurement (off by default; adds two event records per launch)
 void gemm_profile_enable(bool on);
 void gemm_profile_read(double* ms, double* flops, long* launches);
+void gemm_profile_dump(const char* path);
 
 // sum the partials of one GEMM into the GRN apply table
 //   scale[img][n] = gamma[n] * Gx / (mean_n Gx + 1e-6) + 1,  Gx = sqrt(sum x^2)

@@ -31,7 +31,7 @@ struct GemmDev {
 };
 
 template <int TM, int TN, int BK, bool CONV, bool APRO, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
+__global__ __launch_bounds__(256, (TM * TN == 1 ? 6 : TM * TN == 2 ? 5 : TM * TN == 3 ? 4 : TM * TN == 4 ? 3 : 2)) void gemm_f32_kernel(const GemmDev g) {
   constexpr int BM = 128 * TM, BN = 32 * TN, LS = BK + 4;
   constexpr int KQ = BK / 4;      // float4 per staged row
   constexpr int RPP = 256 / KQ;   // rows staged per pass
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
       if (APRO) {
         if (a_ok[i] && kok) {
           const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.a_scale + a_srow[i] + k);
-          const f32x4 h4 = *reinterpret_cast<const f32x4*>(p.a_shift + k);
-          v = v * s4 + h4;
+          v = v * s4;
+          if (p.a_shift != nullptr) v = v + *reinterpret_cast<const f32x4*>(p.a_shift + k);
         }
       }
       ra[i] = v;
@@ -161,6 +161,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
   const int arow = wave * 32 * TM + col;
   const int kh4 = 4 * half;
 
+  // a wave whose rows all lie beyond M (ragged last tile, tiny-M problems) skips its MFMAs
+  const bool wave_active = bm0 + wave * 32 * TM < M_eff;
   const int nk = (p.K + BK - 1) / BK;
   load_tile(0);
   store_tile(0);
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
     if (kt + 1 < nk) load_tile(kt + 1);
     const float* Ab = As + cur * BM * LS;
     const float* Bb = Bs + cur * BN * LS;
+    if (wave_active) {
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       // lane half h holds k = kk*8 + 4h + j in element j; A and B use the same
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDev g) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
     }
     if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
@@ -325,6 +329,8 @@ struct GemmProf {
   size_t used = 0;
   double flops = 0;
   long launches = 0;
+  struct Rec { int M, N, K, KH, stride, batch, act, apro, grn, topk; };
+  std::vector<Rec> recs;
 } g_prof;
 }  // namespace
 
@@ -333,6 +339,25 @@ void gemm_profile_enable(bool on) {
   g_prof.used = 0;
   g_prof.flops = 0;
   g_prof.launches = 0;
+  g_prof.recs.clear();
+}
+
+// per-launch table (shape, ms, TFLOP/s) of everything recorded since enable; tuning aid
+void gemm_profile_dump(const char* path) {
+  FILE* f = fopen(path, "w");
+  MTGV_CHECK(f != nullptr, ERR_RUNTIME, "cannot open %s", path);
+  fprintf(f, "idx,M,N,K,KH,stride,batch,act,apro,grn,topk,tm,tn,bk,ms,tflops\n");
+  for (size_t i = 0; i + 1 < g_prof.used && i / 2 < g_prof.recs.size(); i += 2) {
+    HIP_OK(hipEventSynchronize(g_prof.ev[i + 1]));
+    float t = 0.f;
+    HIP_OK(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+    const auto& r = g_prof.recs[i / 2];
+    const GemmPlan pl = r.topk ? GemmPlan{1, 2, 16, 0, 0} : gemm_plan(r.M, r.N, r.K, r.act != 0);
+    const double fl = 2.0 * r.M * r.N * r.K * r.batch;
+    fprintf(f, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i / 2, r.M, r.N, r.K, r.KH, r.stride, r.batch, r.act,
+            r.apro, r.grn, r.topk, pl.tm, pl.tn, pl.bk, t, fl / (t * 1e-3) / 1e12);
+  }
+  fclose(f);
 }
 
 void gemm_profile_read(double* ms, double* flops, long* launches) {
@@ -358,6 +383,7 @@ static void prof_begin(const GemmArgs& a, hipStream_t s) {
   HIP_OK(hipEventRecord(g_prof.ev[g_prof.used], s));
   g_prof.flops += 2.0 * (double)a.M * a.N * a.K * a.batch;
   g_prof.launches += 1;
+  g_prof.recs.push_back({a.M, a.N, a.K, a.KH, a.stride, a.batch, a.act, a.a_scale != nullptr, a.grn_part != nullptr, a.topk});
 }
 static void prof_end(hipStream_t s) {
   if (!g_prof.on) return;
@@ -365,7 +391,7 @@ static void prof_end(hipStream_t s) {
   g_prof.used += 2;
 }
 
-GemmPlan gemm_plan(int M, int N, int K) {
+GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue) {
   GemmPlan pl;
   if (const char* e = getenv("MTGV_GEMM_TILE")) {
     int tm = 0, tn = 0, bk = 0;
@@ -377,19 +403,25 @@ GemmPlan gemm_plan(int M, int N, int K) {
       return pl;
     }
   }
-  // widest column tile with the least padding (ties -> wider)
+  // Cost model fitted to tile sweeps on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt):
+  // narrow tiles with BK = 16 win - more resident blocks per CU overlap one block's tile load and
+  // epilogue with another's MFMAs - and whole rounds over the 256 CUs matter more than tile width.
+  //   cost = rounds(tiles / 256 CUs) * BM * BN * (K + per-tile overhead in K-equivalents) / efficiency(tn)
+  const double ov = 36.0 + (heavy_epilogue ? 48.0 : 0.0);
+  static const double eff_plain[6] = {0, 0.88, 0.93, 1.00, 0.80, 0.62};
+  static const double eff_heavy[6] = {0, 0.93, 1.00, 0.99, 0.85, 0.65};
   int best_tn = 1;
-  long best_pad = -1;
+  double best = -1;
+  const long tiles_m = ceil_div(M, 128);
   for (int tn = 1; tn <= 5; ++tn) {
-    const long padded = (long)ceil_div(N, 32 * tn) * 32 * tn;
-    // a 160-wide tile only when it divides N exactly (it costs occupancy)
-    if (tn == 5 && padded != N) continue;
-    if (best_pad < 0 || padded < best_pad || (padded == best_pad && tn >= best_tn)) best_pad = padded, best_tn = tn;
+    const long tiles = tiles_m * ceil_div(N, 32 * tn);
+    const double rounds = (double)((tiles + 255) / 256);
+    const double cost = rounds * 128.0 * 32.0 * tn * ((double)K + ov) / (heavy_epilogue ? eff_heavy[tn] : eff_plain[tn]);
+    if (best < 0 || cost < best) best = cost, best_tn = tn;
   }
   pl.tm = 1;
   pl.tn = best_tn;
-  const int rem = K % 32;
-  pl.bk = (pl.tn >= 5 || (rem > 0 && rem <= 16)) ? 16 : 32;
+  pl.bk = 16;
   pl.tiles_m = ceil_div(M, pl.bm());
   pl.tiles_n = ceil_div(N, pl.bn());
   return pl;
@@ -420,15 +452,15 @@ static void launch_variant(const GemmDev& g, bool conv, bool apro, int grid, hip
   }
 }
 
-// match path: scores + per-tile top-k, one tile shape (128 queries x 128 bank rows, BK 32)
+// match path: scores + per-tile top-k, one tile shape (128 queries x 64 bank rows, BK 16)
 static void launch_topk(const GemmDev& g, int grid, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * (128 + 128) * (32 + 4) * sizeof(float);
+  constexpr size_t lds = (size_t)2 * (128 + 64) * (16 + 4) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<1, 4, 32, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<1, 2, 16, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 32, false, false, 1>), dim3(grid), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<1, 2, 16, false, false, 1>), dim3(grid), dim3(256), lds, s, g);
 }
 
 void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
@@ -461,7 +493,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
 
   prof_begin(a, s);
   if (a.topk > 0) {
-    MTGV_CHECK(pl.tm == 1 && pl.tn == 4 && pl.bk == 32 && !conv && !apro, ERR_INVALID, "gemm: top-k epilogue needs the 128x128x32 tile");
+    MTGV_CHECK(pl.tm == 1 && pl.tn == 2 && pl.bk == 16 && !conv && !apro, ERR_INVALID, "gemm: top-k epilogue needs the 128x64x16 tile");
     MTGV_CHECK(a.cand_s != nullptr && a.cand_i != nullptr && a.topk <= 128, ERR_INVALID, "gemm: bad top-k arguments");
     launch_topk(g, grid, s);
     HIP_OK(hipGetLastError());

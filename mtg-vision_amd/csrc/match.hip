@@ -91,10 +91,10 @@ void Bank::topk(const float* q, int b, int k, int64_t id_base, int64_t* ids, flo
   MTGV_CHECK(q != nullptr && ids != nullptr && scores != nullptr, ERR_INVALID, "bank: null tensor");
   MTGV_CHECK(size_ > 0, ERR_RUNTIME, "bank is empty");
   GemmPlan pl;
-  pl.tm = 1, pl.tn = 4, pl.bk = 32;
+  pl.tm = 1, pl.tn = 2, pl.bk = 16;
   pl.tiles_m = ceil_div(b, pl.bm());
   pl.tiles_n = ceil_div((int)size_, pl.bn());
-  const int kt = k < pl.bn() ? k : pl.bn();  // a 128-column tile cannot contribute more than 128 candidates
+  const int kt = k < pl.bn() ? k : pl.bn();  // a 64-column tile cannot contribute more than 64 candidates
   const size_t ncand = (size_t)pl.tiles_n * kt;
   qn_.ensure((size_t)b * dim_);
   cand_s_.ensure((size_t)b * ncand);

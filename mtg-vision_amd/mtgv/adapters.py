@@ -130,6 +130,18 @@ def _min_area_rect(points: np.ndarray) -> np.ndarray:
     return np.asarray([ux * a0 + uy * b0, ux * a1 + uy * b0, ux * a1 + uy * b1, ux * a0 + uy * b1])
 
 
+def _poly_centroid(p: np.ndarray) -> np.ndarray:
+    """area centroid of a simple polygon (shoelace); falls back to the vertex mean for degenerate input"""
+    p = np.asarray(p, np.float64)
+    x, y = p[:, 0], p[:, 1]
+    xn, yn = np.roll(x, -1), np.roll(y, -1)
+    cr = x * yn - xn * y
+    a = cr.sum() / 2.0
+    if abs(a) < 1e-9:
+        return p.mean(0)
+    return np.asarray([((x + xn) * cr).sum(), ((y + yn) * cr).sum()]) / (6.0 * a)
+
+
 @dataclass
 class InstanceSeg:
     points: np.ndarray
@@ -182,7 +194,7 @@ class InstanceSeg:
             hull = box
         # orig centroid - closed centroid (od_export.py:69-71): the card's bottom is missing from the mask,
         # so this vector points at the card's top edge
-        v = pts.mean(0) - hull.mean(0)
+        v = _poly_centroid(pts) - _poly_centroid(hull)
         nv = np.linalg.norm(v)
         v = v / nv if nv > 0 else np.asarray([0.0, -1.0])
         # the edge the ray centre + t*v crosses becomes edge (0,1) = top of the de-warped card (od_export.py:77-88)

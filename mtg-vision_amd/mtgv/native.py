@@ -53,6 +53,7 @@ SIGNATURES = {
     "mtgv_device_count": (C.c_int, []),
     "mtgv_profile_gemm": (C.c_int, [c_i32]),
     "mtgv_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64)]),
+    "mtgv_profile_gemm_dump": (C.c_int, [C.c_char_p]),
     "mtgv_encoder_create": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(c_vp)]),
     "mtgv_encoder_destroy": (None, [c_vp]),
     "mtgv_encoder_set_param": (C.c_int, [c_vp, C.c_char_p, c_vp, c_i64]),
