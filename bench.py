@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -55,11 +55,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run (see docstring)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the recognition path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box: MTGV_SHARE_GPU=1 maps every rank to device 0 and MTGV_DIST_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); the driver's real runs use neither
+    share = os.environ.get("MTGV_SHARE_GPU") == "1"
+    backend = os.environ.get("MTGV_DIST_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mtgv import dist as mdist
     from mtgv import native, spec
@@ -90,7 +98,13 @@ def main():
     assert len(matcher) == hi - lo
 
     if sharded:
-        match_fn = lambda z, k: mdist.sharded_topk(z, k, matcher.match, merge_topk)  # noqa: E731
+        if backend == "nccl":
+            match_fn = lambda z, k: mdist.sharded_topk(z, k, matcher.match, merge_topk)  # noqa: E731
+        else:  # gloo rehearsal: collectives on host copies
+            def match_fn(z, k):
+                loc = lambda q, kk: tuple(t.cpu() for t in matcher.match(q.to(dev), kk))  # noqa: E731
+                mrg = lambda cs, ci, kk: merge_topk(cs.to(dev), ci.to(dev), kk)  # noqa: E731
+                return mdist.sharded_topk(z.cpu(), k, loc, mrg)
     else:
         match_fn = None
     pipe = Pipeline(detector, encoder, matcher, K, 1, match_fn)
@@ -112,7 +126,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     cards = world * F * K * a.steps
@@ -184,7 +198,7 @@ def main():
             # bounded CPU sample of the same workload on the host cores: the oracle pipeline
             from oracle import pipeline_ref
 
-            nthreads = os.cpu_count() or 1
+            nthreads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
             torch.set_num_threads(nthreads)
             cf = min(a.cpu_frames, F)
             bank_cpu = matcher.rows(0, len(matcher))
