@@ -187,6 +187,13 @@ MTGV_API int mtgv_warp_quads(const uint8_t* frames_dev, int32_t nf, int32_t fh, 
 /* out[M,N] = act(A[M,K] W[N,K]^T + bias) (+res);  act: 0 none 1 gelu 2 mish 3 silu 4 sigmoid */
 MTGV_API int mtgv_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
                             int32_t m, int32_t n, int32_t k, int32_t act, void* stream);
+/* linear with the block's fused extras: rows are grouped in images of hw rows; a_scale (m/hw, k) and a_shift (k)
+ * or NULL are applied to A on load (GRN apply); grn_part or NULL receives the per-tile sum(out^2) partials
+ * (mtgv_op_linear_ex_part_floats floats). */
+MTGV_API int64_t mtgv_op_linear_ex_part_floats(int32_t m, int32_t n, int32_t k, int32_t act, int32_t hw);
+MTGV_API int mtgv_op_linear_ex(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
+                               int32_t m, int32_t n, int32_t k, int32_t act, int32_t hw, const float* a_scale_dev,
+                               const float* a_shift_dev, float* grn_part_dev, void* stream);
 /* NHWC conv, weight (cout, kh, kw, cin), zero padding */
 MTGV_API int mtgv_op_conv2d(const float* x_dev, const float* w_dev, const float* bias_dev, float* out_dev, int32_t n, int32_t h,
                             int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,

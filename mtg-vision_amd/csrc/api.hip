@@ -149,6 +149,29 @@ MTGV_API int mtgv_op_linear(const float* a_dev, const float* w_dev, const float*
     gemm_launch(g, gemm_plan(m, n, k, act != 0), (hipStream_t)stream);
   });
 }
+MTGV_API int64_t mtgv_op_linear_ex_part_floats(int32_t m, int32_t n, int32_t k, int32_t act, int32_t hw) {
+  if (m <= 0 || n <= 0 || k <= 0 || hw <= 0) return 0;
+  return (int64_t)gemm_grn_part_floats(gemm_plan(m, n, k, act != 0), n, hw);
+}
+MTGV_API int mtgv_op_linear_ex(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
+                               int32_t m, int32_t n, int32_t k, int32_t act, int32_t hw, const float* a_scale_dev,
+                               const float* a_shift_dev, float* grn_part_dev, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(a_dev && w_dev && out_dev, ERR_INVALID, "null argument");
+    GemmArgs g = linear_args(a_dev, k, w_dev, bias_dev, out_dev, n, m, n, k, act);
+    g.res = res_dev;
+    g.ldr = n;
+    g.hw = hw;
+    g.a_scale = a_scale_dev;
+    g.a_shift = a_shift_dev;
+    const GemmPlan pl = gemm_plan(m, n, k, act != 0);
+    if (grn_part_dev) {
+      g.grn_part = grn_part_dev;
+      g.segmax = gemm_grn_segmax(pl, hw);
+    }
+    gemm_launch(g, pl, (hipStream_t)stream);
+  });
+}
 MTGV_API int mtgv_op_conv2d(const float* x_dev, const float* w_dev, const float* bias_dev, float* out_dev, int32_t n, int32_t h,
                             int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                             int32_t act, void* stream) {

@@ -30,8 +30,8 @@ struct GemmDev {
   int remap;  // output rows are not simply m
 };
 
-template <int TM, int TN, int BK, bool CONV, bool APRO, int EPI>
-__global__ __launch_bounds__(256, (TM * TN == 1 ? 6 : TM * TN == 2 ? 5 : TM * TN == 3 ? 4 : TM * TN == 4 ? 3 : 2)) void gemm_f32_kernel(const GemmDev g) {
+template <int TM, int TN, int BK, bool CONV, bool APRO, int EPI, int ACT>
+__global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN == 2 ? (BK == 16 ? 5 : 4) : TM * TN == 3 ? (BK == 16 ? 4 : 3) : TM * TN == 4 ? (BK == 16 ? 3 : 2) : 2)) void gemm_f32_kernel(const GemmDev g) {
   constexpr int BM = 128 * TM, BN = 32 * TN, LS = BK + 4;
   constexpr int KQ = BK / 4;      // float4 per staged row
   constexpr int RPP = 256 / KQ;   // rows staged per pass
@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? 6 : TM * TN == 2 ? 5 : TM * TN
   }
 
   f32x4 ra[AP], rb[BP];
+  f32x4 rs[APRO ? AP : 1];
+  int k_staged = 0;
   auto load_tile = [&](int kt) {
     const int k = kt * BK + lk;
+    k_staged = k;
     const bool kok = k < p.K;
     int kh = 0, kw = 0, c = 0;
     if (CONV) {
@@ -125,11 +128,11 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? 6 : TM * TN == 2 ? 5 : TM * TN
         if (a_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(Ap + a_row[i] + k);
       }
       if (APRO) {
-        if (a_ok[i] && kok) {
-          const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.a_scale + a_srow[i] + k);
-          v = v * s4;
-          if (p.a_shift != nullptr) v = v + *reinterpret_cast<const f32x4*>(p.a_shift + k);
-        }
+        // only fetch the GRN multiplier here; it is applied in store_tile so that this wave does not
+        // wait for the loads before its MFMA phase
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+        if (a_ok[i] && kok) s4 = *reinterpret_cast<const f32x4*>(p.a_scale + a_srow[i] + k);
+        rs[i] = s4;
       }
       ra[i] = v;
     }
@@ -142,8 +145,14 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? 6 : TM * TN == 2 ? 5 : TM * TN
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i)
-      *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + i * RPP) * LS + lk]) = ra[i];
+    for (int i = 0; i < AP; ++i) {
+      f32x4 v = ra[i];
+      if (APRO) {
+        v = v * rs[i];
+        if (p.a_shift != nullptr && a_ok[i] && k_staged < p.K) v = v + *reinterpret_cast<const f32x4*>(p.a_shift + k_staged);
+      }
+      *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + i * RPP) * LS + lk]) = v;
+    }
 #pragma unroll
     for (int i = 0; i < BP; ++i)
       if (lrow + i * RPP < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + i * RPP) * LS + lk]) = rb[i];
@@ -243,41 +252,90 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? 6 : TM * TN == 2 ? 5 : TM * TN
   }
 
   // ---- epilogue: bias, activation, residual, store (C layout: col = lane&31,
-  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  ACT >= 0 fixes the activation at compile time. ----
+  auto activate = [&](float x) -> float {
+    if constexpr (ACT == ACT_NONE) return x;
+    else if constexpr (ACT == ACT_GELU) return act_gelu(x);
+    else if constexpr (ACT == ACT_MISH) return act_mish(x);
+    else if constexpr (ACT == ACT_SILU) return act_silu(x);
+    else return apply_act(x, p.act);
+  };
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool interior = (bm0 + BM <= M_eff) && (bn0 + BN <= p.N) && !g.remap && p.crop_boxes == nullptr;
+  if (interior) {
+    // Whole tile inside the problem, rows map 1:1: no per-element predicates, and every address is
+    // (wave-uniform base) + (32-bit lane offset), so stores/loads need no per-element address VALU.
+    const long row0 = (long)bm0 + (long)wave_u * 32 * TM;
+    float* const obase = Op + row0 * p.ldo + p.o_off + bn0;
+    const unsigned loff = (unsigned)(4 * half) * (unsigned)p.ldo + (unsigned)col;
+    float bv[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = bn0 + j * 32 + col;
-    const bool nok = n < p.N;
-    const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+    for (int j = 0; j < TN; ++j) bv[j] = p.bias != nullptr ? p.bias[bn0 + j * 32 + col] : 0.f;
+    if (p.res != nullptr) {
+      const float* const rbase = p.res + row0 * p.ldr + bn0;
+      const unsigned roff = (unsigned)(4 * half) * (unsigned)p.ldr + (unsigned)col;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = bm0 + wave * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = 0.f;
-        if (m < M_eff && nok) {
-          v = apply_act(acc[i][j][r] + bv, p.act);
-          if (p.crop_boxes != nullptr) {
-            const float* bx = p.crop_boxes + ((long)z * p.crop_rows + m) * 4;
-            const uint32_t py = fdiv((uint32_t)n, g.d_cw);
-            const float fx = (float)((uint32_t)n - py * (uint32_t)p.crop_w), fy = (float)py;
-            const bool inside = fx >= __fmul_rn(bx[0], p.crop_scale) && fx < __fmul_rn(bx[2], p.crop_scale) &&
-                                fy >= __fmul_rn(bx[1], p.crop_scale) && fy < __fmul_rn(bx[3], p.crop_scale);
-            if (!inside) v = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const long rr = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float v = activate(acc[i][j][r] + bv[j]);
+            (obase + rr * p.ldo + j * 32)[loff] = v + (rbase + rr * p.ldr + j * 32)[roff];
+            acc[i][j][r] = v;
           }
-          float o = v;
-          if (p.res != nullptr) o += p.res[(long)m * p.ldr + n];
-          long orow = m;
-          if (g.remap) {
-            const uint32_t img = fdiv((uint32_t)m, g.d_ohw);
-            const uint32_t rem = (uint32_t)m - img * (uint32_t)(p.OH * p.OW);
-            const uint32_t oh = fdiv(rem, g.d_ow);
-            const uint32_t ow = rem - oh * (uint32_t)p.OW;
-            orow = ((long)img * p.OH2 + oh * p.os + p.oy) * p.OW2 + ow * p.os + p.ox;
-          }
-          Op[orow * p.ldo + p.o_off + n] = o;
         }
-        acc[i][j][r] = v;
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long rr = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float v = activate(acc[i][j][r] + bv[j]);
+            (obase + rr * p.ldo + j * 32)[loff] = v;
+            acc[i][j][r] = v;
+          }
+        }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = bn0 + j * 32 + col;
+      const bool nok = n < p.N;
+      const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = bm0 + wave * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = 0.f;
+          if (m < M_eff && nok) {
+            v = activate(acc[i][j][r] + bv);
+            if (p.crop_boxes != nullptr) {
+              const float* bx = p.crop_boxes + ((long)z * p.crop_rows + m) * 4;
+              const uint32_t py = fdiv((uint32_t)n, g.d_cw);
+              const float fx = (float)((uint32_t)n - py * (uint32_t)p.crop_w), fy = (float)py;
+              const bool inside = fx >= __fmul_rn(bx[0], p.crop_scale) && fx < __fmul_rn(bx[2], p.crop_scale) &&
+                                  fy >= __fmul_rn(bx[1], p.crop_scale) && fy < __fmul_rn(bx[3], p.crop_scale);
+              if (!inside) v = 0.f;
+            }
+            float o = v;
+            if (p.res != nullptr) o += p.res[(long)m * p.ldr + n];
+            long orow = m;
+            if (g.remap) {
+              const uint32_t img = fdiv((uint32_t)m, g.d_ohw);
+              const uint32_t rem = (uint32_t)m - img * (uint32_t)(p.OH * p.OW);
+              const uint32_t oh = fdiv(rem, g.d_ow);
+              const uint32_t ow = rem - oh * (uint32_t)p.OW;
+              orow = ((long)img * p.OH2 + oh * p.os + p.oy) * p.OW2 + ow * p.os + p.ox;
+            }
+            Op[orow * p.ldo + p.o_off + n] = o;
+          }
+          acc[i][j][r] = v;
+        }
       }
     }
   }
@@ -288,19 +346,27 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? 6 : TM * TN == 2 ? 5 : TM * TN
     const int m_end = (bm0 + BM < M_eff) ? bm0 + BM : M_eff;
     const int img_first = (int)fdiv((uint32_t)bm0, g.d_hw);
     const int img_last = (int)fdiv((uint32_t)(m_end - 1), g.d_hw);
+    const bool one_image = interior && img_first == img_last;  // every row of the tile in one image: no row tests
     for (int s = 0; s <= img_last - img_first; ++s) {
       const int lo = (img_first + s) * p.hw, hi = lo + p.hw;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         float sum = 0.f;
+        if (one_image) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = bm0 + wave * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float v = acc[i][j][r];
-            sum += (m >= lo && m < hi) ? v * v : 0.f;
-          }
+            for (int r = 0; r < 16; ++r) sum += acc[i][j][r] * acc[i][j][r];
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = bm0 + wave * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              const float v = acc[i][j][r];
+              sum += (m >= lo && m < hi) ? v * v : 0.f;
+            }
+        }
         sum += __shfl_xor(sum, 32);
         if (half == 0) red[wave * BN + j * 32 + col] = sum;
       }
@@ -421,7 +487,7 @@ GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue) {
   }
   pl.tm = 1;
   pl.tn = best_tn;
-  pl.bk = 16;
+  pl.bk = (best_tn == 1 && K >= 256) ? 32 : 16;  // sweep: BK 32 pays only for the narrowest tile on long K
   pl.tiles_m = ceil_div(M, pl.bm());
   pl.tiles_n = ceil_div(N, pl.bn());
   return pl;
@@ -433,35 +499,40 @@ size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw) {
   return (size_t)p.tiles_m * gemm_grn_segmax(p, hw) * N;
 }
 
-template <int TM, int TN, int BK>
-static void launch_variant(const GemmDev& g, bool conv, bool apro, int grid, hipStream_t s) {
+template <int TM, int TN, int BK, bool CONV, bool APRO, int EPI, int ACT>
+static void launch_one(const GemmDev& g, int grid, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (128 * TM + 32 * TN) * (BK + 4) * sizeof(float);
   static bool attr_done = false;  // >64 KiB of dynamic LDS must be opted into once per kernel
   if (!attr_done) {
-    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<TM, TN, BK, false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<TM, TN, BK, true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<TM, TN, BK, false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<TM, TN, BK, CONV, APRO, EPI, ACT>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
+  hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, CONV, APRO, EPI, ACT>), dim3(grid, g.a.batch), dim3(256), lds, s, g);
+}
+
+// activation fixed at compile time for the combinations the path uses; anything else takes the
+// runtime-switch instance (ACT = -1)
+template <int TM, int TN, int BK>
+static void launch_variant(const GemmDev& g, bool conv, bool apro, int grid, hipStream_t s) {
+  const int act = g.a.act;
   if (apro) {
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, false, true, 0>), dim3(grid, g.a.batch), dim3(256), lds, s, g);
+    launch_one<TM, TN, BK, false, true, 0, ACT_NONE>(g, grid, s);
   } else if (conv) {
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, true, false, 0>), dim3(grid, g.a.batch), dim3(256), lds, s, g);
+    if (act == ACT_SILU) launch_one<TM, TN, BK, true, false, 0, ACT_SILU>(g, grid, s);
+    else if (act == ACT_NONE) launch_one<TM, TN, BK, true, false, 0, ACT_NONE>(g, grid, s);
+    else launch_one<TM, TN, BK, true, false, 0, -1>(g, grid, s);
   } else {
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, false, false, 0>), dim3(grid, g.a.batch), dim3(256), lds, s, g);
+    if (act == ACT_NONE) launch_one<TM, TN, BK, false, false, 0, ACT_NONE>(g, grid, s);
+    else if (act == ACT_MISH) launch_one<TM, TN, BK, false, false, 0, ACT_MISH>(g, grid, s);
+    else if (act == ACT_GELU) launch_one<TM, TN, BK, false, false, 0, ACT_GELU>(g, grid, s);
+    else if (act == ACT_SILU) launch_one<TM, TN, BK, false, false, 0, ACT_SILU>(g, grid, s);
+    else launch_one<TM, TN, BK, false, false, 0, -1>(g, grid, s);
   }
 }
 
 // match path: scores + per-tile top-k, one tile shape (128 queries x 64 bank rows, BK 16)
-static void launch_topk(const GemmDev& g, int grid, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * (128 + 64) * (16 + 4) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<1, 2, 16, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((gemm_f32_kernel<1, 2, 16, false, false, 1>), dim3(grid), dim3(256), lds, s, g);
-}
+static void launch_topk(const GemmDev& g, int grid, hipStream_t s) { launch_one<1, 2, 16, false, false, 1, ACT_NONE>(g, grid, s); }
 
 void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   MTGV_CHECK(a.batch >= 1 && a.batch <= 65535, ERR_INVALID, "gemm: batch=%d", a.batch);
@@ -474,6 +545,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   const bool conv = !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.stride_w <= 1 && a.pad == 0);
   const bool apro = a.a_scale != nullptr;
   MTGV_CHECK(!(apro && conv), ERR_INVALID, "gemm: GRN prologue only on 1x1");
+  MTGV_CHECK(!(apro && a.act != ACT_NONE), ERR_INVALID, "gemm: GRN prologue is only combined with a linear epilogue");
   if (!conv) MTGV_CHECK(a.OH == a.H && a.OW == a.Wd, ERR_INVALID, "gemm: 1x1 geometry mismatch");
   if (apro || a.grn_part) MTGV_CHECK(a.hw > 0 && a.M % a.hw == 0, ERR_INVALID, "gemm: hw=%d must divide M=%d", a.hw, a.M);
   if (a.grn_part) MTGV_CHECK(a.segmax >= gemm_grn_segmax(pl, a.hw), ERR_INVALID, "gemm: segmax too small");
@@ -508,9 +580,10 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
     prof_end(s);                                                   \
     return;                                                        \
   }
-  MTGV_CASE(1, 1, 16) MTGV_CASE(1, 2, 16) MTGV_CASE(1, 3, 16) MTGV_CASE(1, 4, 16) MTGV_CASE(1, 5, 16)
-  MTGV_CASE(1, 1, 32) MTGV_CASE(1, 2, 32) MTGV_CASE(1, 3, 32) MTGV_CASE(1, 4, 32)
-  MTGV_CASE(2, 2, 16) MTGV_CASE(2, 2, 32)
+  MTGV_CASE(1, 1, 16) MTGV_CASE(1, 2, 16) MTGV_CASE(1, 3, 16) MTGV_CASE(1, 4, 16) MTGV_CASE(1, 5, 16) MTGV_CASE(1, 1, 32)
+#ifdef MTGV_ALL_TILES  // sweep-only shapes (tools/gemm_sweep.py); never chosen by gemm_plan
+  MTGV_CASE(1, 2, 32) MTGV_CASE(1, 3, 32) MTGV_CASE(1, 4, 32) MTGV_CASE(2, 2, 16) MTGV_CASE(2, 2, 32)
+#endif
 #undef MTGV_CASE
   MTGV_CHECK(false, ERR_INVALID, "gemm: no kernel for tile tm=%d tn=%d bk=%d", pl.tm, pl.tn, pl.bk);
 }
