@@ -133,7 +133,16 @@ template <int TW>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ in, const float* __restrict__ w49,
                                                      const float* __restrict__ bias, float* __restrict__ out, int N, int H, int W,
                                                      int C, int nstrips, long total) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  // XCD-aware block order: blocks that share an XCD (equal blockIdx % 8) walk a contiguous run of
+  // rows, so the 6 halo rows an output row shares with its neighbours are re-read from that XCD's L2
+  // instead of being fetched again by every XCD (measured 3.3x the algorithmic reads without this).
+  long blk;
+  {
+    const long nwg = gridDim.x, b = blockIdx.x;
+    const long q = nwg >> 3, r = nwg & 7, x = b & 7;
+    blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  const long idx = blk * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c4n = C >> 2;
   const int c4 = (int)(idx % c4n);

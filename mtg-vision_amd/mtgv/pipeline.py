@@ -35,12 +35,8 @@ class Pipeline:
         reps = (self.K + _PAD_BOXES.shape[0] - 1) // _PAD_BOXES.shape[0]
         self._pad = _PAD_BOXES.repeat(reps, 1)[: self.K].to(detector.device)
 
-    def run(self, frames_u8: torch.Tensor, flip_rgb: bool = True):
-        """frames (F, 640, 640, 3) uint8 on the GPU -> dict with ids (F, K, top_k) int64, scores, n_det (F,)
-        and the intermediate crops / embeddings (device tensors)."""
-        F = frames_u8.shape[0]
-        K = self.K
-        det = self.detector.forward(frames_u8, flip_rgb, mask_rows=K)
+    def _embed_match(self, frames_u8: torch.Tensor, det):
+        F, K = frames_u8.shape[0], self.K
         # the K highest-confidence detections per frame (NMS output is score-descending); pad if fewer
         have = torch.arange(K, device=frames_u8.device)[None, :] < det["n_det"][:, None]
         boxes = torch.where(have[..., None], det["boxes"][:, :K], self._pad[None].expand(F, K, 4))
@@ -58,3 +54,45 @@ class Pipeline:
             "z": z,
             "det": det,
         }
+
+    def run_many(self, batches, flip_rgb: bool = True):
+        """Process a sequence of frame batches with the detect stage of batch i+1 overlapped with the
+        crop/embed/match stages of batch i on a second HIP stream.  The detector's late layers have too few
+        tiles to fill 256 CUs on their own; the encoder's GEMMs of the previous batch fill the gaps.
+        Results are identical to `run` on each batch (same kernels, same order per stream)."""
+        dev = self.detector.device
+        if not hasattr(self, "_s_det"):
+            self._s_det, self._s_enc = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        self._s_det.wait_stream(cur)
+        self._s_enc.wait_stream(cur)
+        outs, pending = [], None
+        for frames in list(batches) + [None]:
+            nxt = None
+            if frames is not None:
+                with torch.cuda.stream(self._s_det):
+                    det = self.detector.forward(frames, flip_rgb, mask_rows=self.K)
+                    ev = torch.cuda.Event()
+                    ev.record(self._s_det)
+                nxt = (frames, det, ev)
+            if pending is not None:
+                pf, pdet, pev = pending
+                with torch.cuda.stream(self._s_enc):
+                    self._s_enc.wait_event(pev)
+                    for t in pdet.values():
+                        if t is not None:
+                            t.record_stream(self._s_enc)
+                    outs.append(self._embed_match(pf, pdet))
+            pending = nxt
+        cur.wait_stream(self._s_det)
+        cur.wait_stream(self._s_enc)
+        for o in outs:
+            for t in (o["ids"], o["scores"], o["z"], o["crops"], o["boxes"]):
+                t.record_stream(cur)
+        return outs
+
+    def run(self, frames_u8: torch.Tensor, flip_rgb: bool = True):
+        """frames (F, 640, 640, 3) uint8 on the GPU -> dict with ids (F, K, top_k) int64, scores, n_det (F,)
+        and the intermediate crops / embeddings (device tensors)."""
+        det = self.detector.forward(frames_u8, flip_rgb, mask_rows=self.K)
+        return self._embed_match(frames_u8, det)

@@ -82,3 +82,29 @@ def test_card_segmenter_and_mask_binarize():
     assert crop.shape == (192, 128, 3) and crop.dtype == np.uint8
 
 
+
+
+def test_pipeline_overlap_equals_sequential():
+    """run_many (two HIP streams, detect of batch i+1 beside embed of batch i) == run on each batch, bit for bit"""
+    from mtgv import spec
+    from mtgv.detector import Detector
+    from mtgv.encoder import Encoder
+    from mtgv.matcher import Matcher
+    from mtgv.pipeline import Pipeline
+
+    det_cfg = spec.DetectorConfig()
+    enc_cfg = spec.encoder_config("cnvnxt2ae_nano")
+    F, K = 2, 4
+    m = Matcher(768, capacity=3000)
+    m.add(np.random.default_rng(2).standard_normal((3000, 768)).astype(np.float32))
+    pipe = Pipeline(Detector(det_cfg, spec.random_detector_state(det_cfg, 3), max_batch=F),
+                    Encoder(enc_cfg, spec.random_encoder_state(enc_cfg, 1), max_batch=F * K), m, K, 3)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    batches = [torch.randint(0, 256, (F, 640, 640, 3), generator=g, device="cuda", dtype=torch.uint8) for _ in range(3)]
+    seq = [pipe.run(b) for b in batches]
+    ovl = pipe.run_many(batches)
+    torch.cuda.synchronize()
+    assert len(ovl) == 3
+    for a, b in zip(seq, ovl):
+        for k in ("ids", "scores", "z", "crops", "boxes", "n_det"):
+            assert torch.equal(a[k], b[k]), k
