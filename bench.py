@@ -163,25 +163,32 @@ def main():
         },
     }
 
-    if rank == 0:
-        L = native.lib()
-        import ctypes as C
+    # roofline leg.  Dominant kernel = gemm_f32_kernel (every conv / linear / bank GEMM of the path).  Every rank
+    # runs two more passes of the same step, one stream, so that each launch is alone on the GPU and bracketed by HIP
+    # events on the stream it is launched on (the sharded match inside the step is a collective: all ranks take part).
+    import ctypes as C
 
+    L = native.lib()
+    prof = None
+    if not a.no_roofline:
+        native.check(L.mtgv_profile_gemm(1))
+        nprof = 2
+        for _ in range(nprof):
+            pipe.run(frames)
+        torch.cuda.synchronize()
+        ms, fl, nl = C.c_double(0), C.c_double(0), C.c_int64(0)
+        native.check(L.mtgv_profile_gemm_read(C.byref(ms), C.byref(fl), C.byref(nl)))
+        native.check(L.mtgv_profile_gemm(0))
+        prof = (ms.value / nprof, fl.value / nprof, int(nl.value // nprof))
+        barrier()
+
+    if rank == 0:
         gflops_enc, dw_enc = encoder.flops_per_image()
         det_flops = detector.flops_per_frame()
         res["config"]["algorithmic_gflop_per_card"] = round((gflops_enc + dw_enc + det_flops / K + 2 * a.bank * 768) / 1e9, 3)
-        if not a.no_roofline:
-            # dominant kernel = gemm_f32_kernel (every conv / linear / bank GEMM of the path): HIP events around
-            # each of its launches, on the stream they run on, over two more passes of the same step
-            native.check(L.mtgv_profile_gemm(1))
-            nprof = 2
-            for _ in range(nprof):
-                pipe.run(frames)
-            torch.cuda.synchronize()
-            ms, fl, nl = C.c_double(0), C.c_double(0), C.c_int64(0)
-            native.check(L.mtgv_profile_gemm_read(C.byref(ms), C.byref(fl), C.byref(nl)))
-            native.check(L.mtgv_profile_gemm(0))
-            ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        if prof is not None:
+            gemm_ms, gemm_fl, launches = prof
+            ach = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")
             if os.path.exists(tfile):
@@ -197,9 +204,11 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": traffic,
-                "launches_per_step": int(nl.value // nprof),
-                "gemm_ms_per_step": round(ms.value / nprof, 3),
-                "algorithmic_gflop_per_step": round(fl.value / nprof / 1e9, 2),
+                "traffic_note": "HBM bytes of these launches per step, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/gemm_traffic.json)",
+                "launches_per_step": launches,
+                "gemm_ms_per_step": round(gemm_ms, 3),
+                "algorithmic_gflop_per_step": round(gemm_fl / 1e9, 2),
+                "measured": "HIP events around every launch on its stream, 2 single-stream passes after the timed region",
             }
         if world == 1 and not a.no_cpu_baseline:
             # bounded CPU sample of the same workload on the host cores: the oracle pipeline

@@ -26,7 +26,7 @@ def test_two_ranks_sharded_bench_runs():
     cmd = [
         sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-        "--frames", "4", "--bank", "20000", "--encoder", "cnvnxt2ae_nano", "--no-roofline",
+        "--frames", "4", "--bank", "20000", "--encoder", "cnvnxt2ae_nano",
     ]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -34,6 +34,7 @@ def test_two_ranks_sharded_bench_runs():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert "row-sharded 2-way" in res["config"]["bank_layout"]
+    assert res["roofline"]["achieved"] > 0  # the roofline leg contains a collective: it must run on every rank
 
 
 def test_sharded_equals_replicated_ids():
