@@ -163,8 +163,13 @@ MTGV_API int mtgv_op_linear_ex(const float* a_dev, const float* w_dev, const flo
     g.ldr = n;
     g.hw = hw;
     g.a_scale = a_scale_dev;
-    g.a_shift = a_shift_dev;
-    const GemmPlan pl = gemm_plan(m, n, k, act != 0);
+    static DevBuf fold_tmp;  // test surface only: shift folded into a temporary bias
+    if (a_shift_dev != nullptr) {
+      fold_tmp.ensure((size_t)n);
+      fold_shift_into_bias_launch(w_dev, a_shift_dev, bias_dev, fold_tmp.p, n, k, (hipStream_t)stream);
+      g.bias = fold_tmp.p;
+    }
+    const GemmPlan pl = gemm_plan(m, n, k, act != 0, a_scale_dev != nullptr);
     if (grn_part_dev) {
       g.grn_part = grn_part_dev;
       g.segmax = gemm_grn_segmax(pl, hw);
@@ -227,6 +232,7 @@ MTGV_API int mtgv_op_block(const float* x_dev, float* out_dev, int32_t n, int32_
     ws.hid = ws.t2 + z.t;
     ws.part = ws.hid + z.hid;
     ws.scale = ws.part + z.part;
+    ws.bfold = ws.scale + z.scale;
     run_block(x_dev, out_dev, n, h, w, c, act, bw, ws, (hipStream_t)stream);
   });
 }

@@ -33,11 +33,11 @@ struct BlockW {
   float* b2_folded = nullptr;
 };
 struct BlockWs {
-  float *t1 = nullptr, *t2 = nullptr, *hid = nullptr, *part = nullptr, *scale = nullptr;
+  float *t1 = nullptr, *t2 = nullptr, *hid = nullptr, *part = nullptr, *scale = nullptr, *bfold = nullptr;
 };
 struct BlockWsSize {
-  size_t t, hid, part, scale;
-  size_t total() const { return 2 * t + hid + part + scale; }
+  size_t t, hid, part, scale, bfold;
+  size_t total() const { return 2 * t + hid + part + scale + bfold; }
 };
 BlockWsSize block_ws_size(int n, int h, int w, int c);
 // Block.forward on NHWC x -> out (may not alias x)

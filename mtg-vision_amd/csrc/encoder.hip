@@ -120,6 +120,7 @@ BlockWsSize block_ws_size(int n, int h, int w, int c) {
   const GemmPlan pl = gemm_plan((int)M, 4 * c, c, true);
   z.part = gemm_grn_part_floats(pl, 4 * c, h * w);
   z.scale = (size_t)n * 4 * c;
+  z.bfold = (size_t)c;
   return z;
 }
 
@@ -143,11 +144,13 @@ void run_block(const float* x, float* out, int n, int h, int w, int c, int act, 
   g2.ldr = c;
   g2.hw = hw;
   g2.a_scale = ws.scale;
-  if (bw.b2_folded != nullptr)
-    g2.bias = bw.b2_folded;  // beta already inside the bias
-  else
-    g2.a_shift = bw.beta;
-  gemm_launch(g2, gemm_plan(M, c, 4 * c), s);
+  if (bw.b2_folded != nullptr) {
+    g2.bias = bw.b2_folded;  // beta already inside the bias (folded at weight load)
+  } else {
+    fold_shift_into_bias_launch(bw.w2, bw.beta, bw.b2, ws.bfold, c, 4 * c, s);
+    g2.bias = ws.bfold;
+  }
+  gemm_launch(g2, gemm_plan(M, c, 4 * c, false, true), s);
 }
 
 // ---------------------------------------------------------------------------
@@ -414,6 +417,7 @@ void Encoder::forward(const void* x, int layout, int n, float* z_out, hipStream_
     ws.hid = ws.t2 + z.t;
     ws.part = ws.hid + z.hid;
     ws.scale = ws.part + z.part;
+    ws.bfold = ws.scale + z.scale;
     for (size_t j = 0; j < blocks_[st].size(); ++j) {
       run_block(cur, alt, n, h, w, c, act_, blocks_[st][j], ws, s);
       std::swap(cur, alt);

@@ -69,10 +69,13 @@ struct GemmPlan {
 };
 
 // heavy_epilogue: the launch applies an activation (transcendentals per output element)
-GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue = false);
+// scaled_a: the launch applies the GRN multiplier to A (a_scale)
+GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue = false, bool scaled_a = false);
 int gemm_grn_segmax(const GemmPlan& p, int hw);
 size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw);
 void gemm_launch(const GemmArgs& a, const GemmPlan& p, hipStream_t s);
+// out[n] = bias[n] + W[n][:] . shift  (GRN beta folded into the next Linear's bias; a_shift is not applied by the GEMM)
+void fold_shift_into_bias_launch(const float* W, const float* shift, const float* bias, float* out, int N, int K, hipStream_t s);
 
 // launch profiler for the roofline measurement (off by default; adds two event records per launch)
 void gemm_profile_enable(bool on);

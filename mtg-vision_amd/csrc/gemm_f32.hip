@@ -16,6 +16,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 namespace mtgv {
@@ -27,7 +28,8 @@ struct GemmDev {
   GemmArgs a;
   FastDiv d_ohw, d_ow, d_cin, d_kwcin, d_hw, d_cw;
   int tiles_m, tiles_n;
-  int remap;  // output rows are not simply m
+  int remap;     // output rows are not simply m
+  int nseg_max;  // APRO: images a 128-row tile can touch (sizes the LDS multiplier tile)
 };
 
 template <int TM, int TN, int BK, bool CONV, bool APRO, int EPI, int ACT>
@@ -71,7 +73,6 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
   const int lrow = tid / KQ, lk = (tid % KQ) * 4;
   long a_row[AP];   // CONV: pixel index of image start; dense: element offset of row
   int a_ih0[AP], a_iw0[AP];
-  long a_srow[AP];  // APRO: element offset of the image's scale row
   bool a_ok[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
@@ -90,7 +91,6 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
       a_row[i] = (long)mm * p.c_total + p.c_off;
       a_ih0[i] = a_iw0[i] = 0;
     }
-    a_srow[i] = APRO ? (long)fdiv(mm, g.d_hw) * p.K : 0;
   }
   long b_row[BP];
   bool b_ok[BP];
@@ -103,11 +103,19 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
   }
 
   f32x4 ra[AP], rb[BP];
-  f32x4 rs[APRO ? AP : 1];
-  int k_staged = 0;
+  // APRO (GRN apply): the multipliers s[img][k] of the images this tile touches are staged per K step into
+  // LDS (Ss[2][nseg][BK]) and applied to the A fragments as they are read - the A loads stay plain.
+  constexpr int SPT = APRO ? (BM * KQ + 255) / 256 : 1;  // multiplier float4s a thread may have to stage
+  f32x4 rsl[SPT];
+  float* Ss = Bs + 2 * BN * LS;
+  const int img_first_t = APRO ? (int)fdiv((uint32_t)bm0, g.d_hw) : 0;
+  int nseg_t = 1;
+  if (APRO) {
+    const int m_end_t = (bm0 + BM < M_eff) ? bm0 + BM : M_eff;
+    nseg_t = (int)fdiv((uint32_t)(m_end_t - 1), g.d_hw) - img_first_t + 1;
+  }
   auto load_tile = [&](int kt) {
     const int k = kt * BK + lk;
-    k_staged = k;
     const bool kok = k < p.K;
     int kh = 0, kw = 0, c = 0;
     if (CONV) {
@@ -127,13 +135,6 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
       } else {
         if (a_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(Ap + a_row[i] + k);
       }
-      if (APRO) {
-        // only fetch the GRN multiplier here; it is applied in store_tile so that this wave does not
-        // wait for the loads before its MFMA phase
-        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-        if (a_ok[i] && kok) s4 = *reinterpret_cast<const f32x4*>(p.a_scale + a_srow[i] + k);
-        rs[i] = s4;
-      }
       ra[i] = v;
     }
 #pragma unroll
@@ -142,20 +143,34 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
       if (b_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(Wp + b_row[i] + k);
       rb[i] = v;
     }
+    if (APRO) {
+#pragma unroll
+      for (int u = 0; u < SPT; ++u) {
+        const int e = tid + u * 256;  // (segment, float4 column) of the multiplier tile
+        const int seg = e / KQ, kq = (e % KQ) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (seg < nseg_t && kt * BK + kq < p.K)
+          v = *reinterpret_cast<const f32x4*>(p.a_scale + (long)(img_first_t + seg) * p.K + kt * BK + kq);
+        rsl[u] = v;
+      }
+    }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      f32x4 v = ra[i];
-      if (APRO) {
-        v = v * rs[i];
-        if (p.a_shift != nullptr && a_ok[i] && k_staged < p.K) v = v + *reinterpret_cast<const f32x4*>(p.a_shift + k_staged);
-      }
+      const f32x4 v = ra[i];
       *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + i * RPP) * LS + lk]) = v;
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i)
       if (lrow + i * RPP < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + i * RPP) * LS + lk]) = rb[i];
+    if (APRO) {
+#pragma unroll
+      for (int u = 0; u < SPT; ++u) {
+        const int e = tid + u * 256;
+        if (e / KQ < nseg_t) *reinterpret_cast<f32x4*>(&Ss[(buf * g.nseg_max + e / KQ) * BK + (e % KQ) * 4]) = rsl[u];
+      }
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -172,6 +187,16 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
 
   // a wave whose rows all lie beyond M (ragged last tile, tiny-M problems) skips its MFMAs
   const bool wave_active = bm0 + wave * 32 * TM < M_eff;
+  int seg_lane[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int sg = 0;
+    if (APRO) {
+      const int m = bm0 + arow + i * 32;
+      sg = (int)fdiv((uint32_t)(m < M_eff ? m : M_eff - 1), g.d_hw) - img_first_t;
+    }
+    seg_lane[i] = sg;
+  }
   const int nk = (p.K + BK - 1) / BK;
   load_tile(0);
   store_tile(0);
@@ -188,7 +213,10 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
       // k assignment, so MFMA j multiplies matching k pairs {j, 4+j}.
       f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&Ab[(arow + i * 32) * LS + kk * 8 + kh4]);
+      for (int i = 0; i < TM; ++i) {
+        a[i] = *reinterpret_cast<const f32x4*>(&Ab[(arow + i * 32) * LS + kk * 8 + kh4]);
+        if (APRO) a[i] = a[i] * *reinterpret_cast<const f32x4*>(&Ss[(cur * g.nseg_max + seg_lane[i]) * BK + kk * 8 + kh4]);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bb[(j * 32 + col) * LS + kk * 8 + kh4]);
 #pragma unroll
@@ -274,16 +302,31 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
     if (p.res != nullptr) {
       const float* const rbase = p.res + row0 * p.ldr + bn0;
       const unsigned roff = (unsigned)(4 * half) * (unsigned)p.ldr + (unsigned)col;
+      // the residual was written several kernels ago: every load is an HBM / Infinity-Cache round trip.
+      // Issue them in two batches of 8 rows ahead of the math and the stores, so the latencies overlap
+      // instead of being paid once per output row.
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long rr = i * 32 + (r & 3) + 8 * (r >> 2);
+        for (int hb = 0; hb < 2; ++hb) {
+          float rv[8][TN];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float v = activate(acc[i][j][r] + bv[j]);
-            (obase + rr * p.ldo + j * 32)[loff] = v + (rbase + rr * p.ldr + j * 32)[roff];
-            acc[i][j][r] = v;
+          for (int q = 0; q < 8; ++q) {
+            const int r = hb * 8 + q;
+            const long rr = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) rv[q][j] = (rbase + rr * p.ldr + j * 32)[roff];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = hb * 8 + q;
+            const long rr = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float v = activate(acc[i][j][r] + bv[j]);
+              (obase + rr * p.ldo + j * 32)[loff] = v + rv[q][j];
+              acc[i][j][r] = v;
+            }
           }
         }
     } else {
@@ -418,7 +461,7 @@ void gemm_profile_dump(const char* path) {
     float t = 0.f;
     HIP_OK(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
     const auto& r = g_prof.recs[i / 2];
-    const GemmPlan pl = r.topk ? GemmPlan{1, 2, 16, 0, 0} : gemm_plan(r.M, r.N, r.K, r.act != 0);
+    const GemmPlan pl = r.topk ? GemmPlan{1, 2, 16, 0, 0} : gemm_plan(r.M, r.N, r.K, r.act != 0, r.apro != 0);
     const double fl = 2.0 * r.M * r.N * r.K * r.batch;
     fprintf(f, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i / 2, r.M, r.N, r.K, r.KH, r.stride, r.batch, r.act,
             r.apro, r.grn, r.topk, pl.tm, pl.tn, pl.bk, t, fl / (t * 1e-3) / 1e12);
@@ -457,7 +500,7 @@ static void prof_end(hipStream_t s) {
   g_prof.used += 2;
 }
 
-GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue) {
+GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue, bool scaled_a) {
   GemmPlan pl;
   if (const char* e = getenv("MTGV_GEMM_TILE")) {
     int tm = 0, tn = 0, bk = 0;
@@ -475,14 +518,15 @@ GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue) {
   //   cost = rounds(tiles / 256 CUs) * BM * BN * (K + per-tile overhead in K-equivalents) / efficiency(tn)
   const double ov = 36.0 + (heavy_epilogue ? 48.0 : 0.0);
   static const double eff_plain[6] = {0, 0.88, 0.93, 1.00, 0.80, 0.62};
-  static const double eff_heavy[6] = {0, 0.93, 1.00, 0.99, 0.85, 0.65};
+  static const double eff_heavy[6] = {0, 0.85, 0.93, 0.98, 1.00, 0.85};
+  static const double eff_scaled[6] = {0, 0.80, 0.90, 1.00, 0.85, 0.80};  // per-fragment GRN multiply amortises over TN
   int best_tn = 1;
   double best = -1;
   const long tiles_m = ceil_div(M, 128);
   for (int tn = 1; tn <= 5; ++tn) {
     const long tiles = tiles_m * ceil_div(N, 32 * tn);
     const double rounds = (double)((tiles + 255) / 256);
-    const double cost = rounds * 128.0 * 32.0 * tn * ((double)K + ov) / (heavy_epilogue ? eff_heavy[tn] : eff_plain[tn]);
+    const double cost = rounds * 128.0 * 32.0 * tn * ((double)K + ov) / (scaled_a ? eff_scaled[tn] : heavy_epilogue ? eff_heavy[tn] : eff_plain[tn]);
     if (best < 0 || cost < best) best = cost, best_tn = tn;
   }
   pl.tm = 1;
@@ -501,11 +545,12 @@ size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw) {
 
 template <int TM, int TN, int BK, bool CONV, bool APRO, int EPI, int ACT>
 static void launch_one(const GemmDev& g, int grid, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * (128 * TM + 32 * TN) * (BK + 4) * sizeof(float);
+  const size_t lds = (size_t)2 * (128 * TM + 32 * TN) * (BK + 4) * sizeof(float) +
+                     (APRO ? (size_t)2 * g.nseg_max * BK * sizeof(float) : 0);
   static bool attr_done = false;  // >64 KiB of dynamic LDS must be opted into once per kernel
   if (!attr_done) {
     HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<TM, TN, BK, CONV, APRO, EPI, ACT>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_done = true;
   }
   hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, CONV, APRO, EPI, ACT>), dim3(grid, g.a.batch), dim3(256), lds, s, g);
@@ -546,6 +591,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   const bool apro = a.a_scale != nullptr;
   MTGV_CHECK(!(apro && conv), ERR_INVALID, "gemm: GRN prologue only on 1x1");
   MTGV_CHECK(!(apro && a.act != ACT_NONE), ERR_INVALID, "gemm: GRN prologue is only combined with a linear epilogue");
+  MTGV_CHECK(a.a_shift == nullptr, ERR_INVALID, "gemm: fold the GRN shift into the bias (fold_shift_into_bias_launch)");
   if (!conv) MTGV_CHECK(a.OH == a.H && a.OW == a.Wd, ERR_INVALID, "gemm: 1x1 geometry mismatch");
   if (apro || a.grn_part) MTGV_CHECK(a.hw > 0 && a.M % a.hw == 0, ERR_INVALID, "gemm: hw=%d must divide M=%d", a.hw, a.M);
   if (a.grn_part) MTGV_CHECK(a.segmax >= gemm_grn_segmax(pl, a.hw), ERR_INVALID, "gemm: segmax too small");
@@ -560,6 +606,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   g.d_cw = make_fastdiv((uint32_t)(a.crop_w > 0 ? a.crop_w : 1));
   g.tiles_m = pl.tiles_m;
   g.tiles_n = pl.tiles_n;
+  g.nseg_max = a.hw > 0 ? std::min(pl.bm(), (pl.bm() - 1) / a.hw + 2) : 1;
   g.remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
   const int grid = pl.tiles_m * pl.tiles_n;
 
@@ -619,6 +666,24 @@ __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restri
   }
   const float denom = red[0] / (float)N + 1e-6f;
   for (int n = tid; n < N; n += 256) scale[(long)img * N + n] = gamma[n] * (gx[n] / denom) + 1.0f;
+}
+
+// out[n] = bias[n] + sum_k W[n][k] * shift[k]: folds GRN's "+ beta" into the bias of the Linear that follows
+__global__ __launch_bounds__(256) void fold_shift_kernel(const float* __restrict__ W, const float* __restrict__ shift,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += W[(long)n * K + k] * shift[k];
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+  if (lane == 0) out[n] = acc + (bias != nullptr ? bias[n] : 0.f);
+}
+
+void fold_shift_into_bias_launch(const float* W, const float* shift, const float* bias, float* out, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(fold_shift_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, shift, bias, out, N, K);
+  HIP_OK(hipGetLastError());
 }
 
 void grn_finalize_launch(const float* part, const GemmPlan& p, int n_img, int hw, int N, const float* gamma, float* scale,

@@ -26,11 +26,16 @@ def run(m, n, k, act, hw, res, scale, shift, grn, tile=None, it=8):
     ms = e0.elapsed_time(e1) / it
     return 2.0 * m * n * k / ms / 1e9
 
-B = 256
-for (c, hw) in ((96, 1536), (192, 384), (384, 96), (768, 24)):
-    m = B * hw
-    print(f"--- C={c} hw={hw} M={m}")
-    print("pw1: plain %.0f | +mish %.0f | +mish+grn %.0f | gelu+grn %.0f" % (
-        run(m, 4*c, c, 0, hw, 0, 0, 0, 0), run(m, 4*c, c, 2, hw, 0, 0, 0, 0), run(m, 4*c, c, 2, hw, 0, 0, 0, 1), run(m, 4*c, c, 1, hw, 0, 0, 0, 1)), flush=True)
-    print("pw2: plain %.0f | +res %.0f | +scale %.0f | +scale+res %.0f | +scale+shift+res %.0f" % (
-        run(m, c, 4*c, 0, hw, 0, 0, 0, 0), run(m, c, 4*c, 0, hw, 1, 0, 0, 0), run(m, c, 4*c, 0, hw, 0, 1, 0, 0), run(m, c, 4*c, 0, hw, 1, 1, 0, 0), run(m, c, 4*c, 0, hw, 1, 1, 1, 0)), flush=True)
+def main():
+    B = 256
+    for (c, hw) in ((96, 1536), (192, 384), (384, 96), (768, 24)):
+        m = B * hw
+        print(f"--- C={c} hw={hw} M={m}")
+        print("pw1: plain %.0f | +mish %.0f | +mish+grn %.0f | gelu+grn %.0f" % (
+            run(m, 4*c, c, 0, hw, 0, 0, 0, 0), run(m, 4*c, c, 2, hw, 0, 0, 0, 0), run(m, 4*c, c, 2, hw, 0, 0, 0, 1), run(m, 4*c, c, 1, hw, 0, 0, 0, 1)), flush=True)
+        print("pw2: plain %.0f | +res %.0f | +scale %.0f | +scale+res %.0f | +scale+shift+res %.0f" % (
+            run(m, c, 4*c, 0, hw, 0, 0, 0, 0), run(m, c, 4*c, 0, hw, 1, 0, 0, 0), run(m, c, 4*c, 0, hw, 0, 1, 0, 0), run(m, c, 4*c, 0, hw, 1, 1, 0, 0), run(m, c, 4*c, 0, hw, 1, 1, 1, 0)), flush=True)
+    
+
+if __name__ == "__main__":
+    main()
