@@ -182,6 +182,17 @@ MTGV_API int mtgv_warp_quads(const uint8_t* frames_dev, int32_t nf, int32_t fh, 
                              uint8_t* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Bank build: card image -> encoder input.                */
+/* Replaces SyntheticBgFgMtgImages.make_cropped (mtgvision/encoder_datasets.py:733-753) */
+/* as used by qdrant_populate.CardProcessor._get_card_point (qdrant_populate.py:84-90). */
+/* ------------------------------------------------------------------------- */
+/* images_dev: n uint8 HWC images of arbitrary sizes back to back; offsets_dev (n) byte offset of each;
+ * hw_dev (n,2) int32 height,width.  Strips ceil(max(0.02 H, 0.02 W)) border pixels, area-resizes to
+ * (out_h, out_w), clips: out_dev (n, out_h, out_w, 3) float32 in [0,1] (feed with MTGV_IN_NHWC_F32). */
+MTGV_API int mtgv_make_cropped(const uint8_t* images_dev, const int64_t* offsets_dev, const int32_t* hw_dev, int32_t n,
+                               int32_t out_h, int32_t out_w, float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Single ops (unit-test and composition surface; same kernels the handles use) */
 /* ------------------------------------------------------------------------- */
 /* out[M,N] = act(A[M,K] W[N,K]^T + bias) (+res);  act: 0 none 1 gelu 2 mish 3 silu 4 sigmoid */

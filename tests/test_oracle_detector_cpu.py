@@ -82,3 +82,32 @@ def test_letterbox_host():
     assert (img[80:560] == 7).all() and (img[:80] == 114).all()
     img, r, (left, top) = letterbox(np.full((1280, 640, 3), 9, np.uint8))
     assert r == 0.5 and (left, top) == (160, 0) and (img[:, 160:480] == 9).all() and (img[:, :160] == 114).all()
+
+
+def test_resize_oracle_against_brute_force():
+    """oracle/resize_ref.make_cropped == direct evaluation of the area integral (small case, pure Python loops)"""
+    from math import ceil
+
+    from oracle import resize_ref as R
+
+    im = np.random.default_rng(1).integers(0, 256, (50, 37, 3), dtype=np.uint8)
+    got = R.make_cropped(im, (12, 8))
+    H, W = im.shape[:2]
+    bw = ceil(max(0.02 * H, 0.02 * W))
+    c = im[bw : H - bw, bw : W - bw].astype(float)
+    sy, sx = c.shape[0] / 12, c.shape[1] / 8
+    ref = np.zeros((12, 8, 3))
+    for oy in range(12):
+        for ox in range(8):
+            for y in range(c.shape[0]):
+                wy = max(0.0, min(y + 1, (oy + 1) * sy) - max(y, oy * sy))
+                for x in range(c.shape[1]):
+                    wx = max(0.0, min(x + 1, (ox + 1) * sx) - max(x, ox * sx))
+                    ref[oy, ox] += wy * wx * c[y, x]
+    ref /= sx * sy * 255
+    assert np.abs(got - ref).max() < 1e-6
+    # integer scale = plain box mean; identity size = copy
+    im = np.random.default_rng(2).integers(0, 256, (2 * 192 + 16, 2 * 128 + 16, 3), dtype=np.uint8)
+    got = R.make_cropped(im, (192, 128))
+    box = im[8:-8, 8:-8].astype(np.float64).reshape(192, 2, 128, 2, 3).mean((1, 3)) / 255
+    assert np.abs(got - box).max() < 1e-6

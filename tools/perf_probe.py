@@ -17,9 +17,9 @@ def timeit(fn, warm=3, it=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
 
-which = sys.argv[1:] or ["ae_tiny", "ae_nano", "plain_tiny", "match"]
+which = sys.argv[1:] or ["ae_tiny", "ae_nano", "plain_tiny", "match", "detector"]
 B = int(os.environ.get("B", 256))
-for name in which:
+for name in [w for w in which if w != "detector"]:
     if name == "match":
         g = torch.Generator(device="cuda").manual_seed(2)
         bank = torch.randn((100_000, 768), generator=g, device="cuda")
@@ -37,3 +37,11 @@ for name in which:
     ms = timeit(lambda: enc.encode(x))
     gf, df = enc.flops_per_image()
     print(f"{name} b={B}: {ms:.2f} ms  {B/ms*1e3:.0f} img/s  gemm {gf*B/ms/1e9:.1f} TFLOP/s ({gf/1e9:.3f} GF/img + dw {df/1e9:.3f})", flush=True)
+
+if "detector" in which:
+    from mtgv.detector import Detector
+    dc = spec.DetectorConfig()
+    det = Detector(dc, spec.random_detector_state(dc, 3), max_batch=32)
+    fr = torch.randint(0, 256, (32, 640, 640, 3), device="cuda", dtype=torch.uint8)
+    ms = timeit(lambda: det.forward(fr, True, 8))
+    print(f"detector b=32: {ms:.2f} ms  {32/ms*1e3:.0f} frames/s  {det.flops_per_frame()*32/ms/1e9:.1f} TFLOP/s ({det.flops_per_frame()/1e9:.2f} GF/frame)", flush=True)
