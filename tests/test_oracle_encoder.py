@@ -115,3 +115,21 @@ def test_predict_hwc_contract():
     assert z.shape == (48,) and z.dtype == np.float32
     z2 = R.predict_hwc(sd, cfg, im.astype(np.float32) / 255.0)
     np.testing.assert_allclose(z, z2, atol=1e-6)
+
+
+def test_key_tables_of_every_variant():
+    """mtgv.spec's state_dict key/shape tables == the reference modules' for all 12 AE sizes x 5 heads and the 8
+    plain sizes (digests captured by tools/make_golden_keys.py from the reference's own factories)."""
+    import hashlib
+    import json
+
+    pinned = json.load(open(os.path.join(GOLDEN, "encoder_key_tables.json")))
+    assert len(pinned) == 12 * 5 + 8
+    for name, rec in pinned.items():
+        model, ht = name.split("|")
+        cfg = spec.encoder_config(model, (224, 224) if ht == "plain" else (192, 128), "conv+linear" if ht == "plain" else ht)
+        items = [(k, tuple(v)) for k, v in spec.encoder_param_shapes(cfg).items()]
+        h = hashlib.sha256()
+        for k, s in items:
+            h.update(f"{k}:{tuple(s)};".encode())
+        assert len(items) == rec["n"] and h.hexdigest() == rec["sha256"], name
