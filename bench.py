@@ -66,7 +66,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            except TypeError:  # older signature without device_id
+                dist.init_process_group("nccl", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
