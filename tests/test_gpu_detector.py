@@ -165,3 +165,41 @@ def test_detector_errors():
     d = Detector(cfg, None, max_batch=1)
     with pytest.raises(RuntimeError):
         d.forward(torch.zeros((1, 640, 640, 3), dtype=torch.uint8, device="cuda"))
+
+
+def test_no_detections_and_other_nc():
+    """frames on which nothing passes conf: n_det = 0 everywhere, the pipeline falls back to its fixed quads;
+    and a 1-class model (nc=1) runs through the same kernels"""
+    from mtgv import spec
+    from mtgv.detector import Detector
+    from mtgv.encoder import Encoder
+    from mtgv.matcher import Matcher
+    from mtgv.pipeline import Pipeline
+    from oracle import detector_ref as D
+
+    cfg = spec.DetectorConfig()
+    sd = spec.random_detector_state(cfg, 3, cls_bias=-12.0)  # class logits far below logit(0.25)
+    det = Detector(cfg, sd, max_batch=2)
+    frames = torch.from_numpy(np.random.default_rng(4).integers(0, 256, (2, 640, 640, 3), dtype=np.uint8)).cuda()
+    out = det.forward(frames, True, 4)
+    assert (out["n_det"] == 0).all()
+    one = det.detect(frames[0].cpu().numpy())
+    assert one.conf.numel() == 0 and one.mask_logits.shape == (0, 160, 160)
+    ecfg = spec.EncoderConfig("ae", (192, 128), 3, 48, (1, 1, 1, 1), (8, 16, 32, 64), "pool+linear", True)
+    m = Matcher(48, capacity=16)
+    m.add(np.random.default_rng(1).standard_normal((16, 48)).astype(np.float32))
+    o = Pipeline(det, Encoder(ecfg, spec.random_encoder_state(ecfg, 1), max_batch=8), m, 4, 1).run(frames)
+    assert o["ids"].shape == (2, 4, 1) and (o["ids"] >= 0).all()
+    assert torch.equal(o["boxes"][0], o["boxes"][1])  # the fixed pad quads
+
+    cfg1 = spec.DetectorConfig(nc=1)
+    sd1 = spec.random_detector_state(cfg1, 5)
+    det1 = Detector(cfg1, sd1, max_batch=1)
+    f1 = np.random.default_rng(6).integers(0, 256, (1, 640, 640, 3), dtype=np.uint8)
+    det1.forward(torch.from_numpy(f1).cuda(), True, 0)
+    pred, protos = det1.raw_outputs(1)
+    rp, rq = D.forward(sd1, cfg1, f1)
+    assert pred.shape == (1, 4 + 1 + 32, 8400)
+    assert np.abs(pred.cpu().numpy()[:, 4:] - rp.numpy()[:, 4:]).max() < 1e-4
+    assert np.abs(pred.cpu().numpy()[:, :4] - rp.numpy()[:, :4]).max() < 640 * 1e-4
+    assert np.abs(protos.cpu().numpy() - rq.numpy()).max() < 1e-4
