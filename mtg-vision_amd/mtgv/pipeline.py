@@ -31,7 +31,6 @@ class Pipeline:
         self.K = int(cards_per_frame)
         self.top_k = int(top_k)
         self.match_fn = match_fn or (lambda z, k: matcher.match(z, k))
-        assert tuple(encoder.cfg.image_hw) == (192, 128) or True
         reps = (self.K + _PAD_BOXES.shape[0] - 1) // _PAD_BOXES.shape[0]
         self._pad = _PAD_BOXES.repeat(reps, 1)[: self.K].to(detector.device)
 
