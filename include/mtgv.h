@@ -89,6 +89,10 @@ MTGV_API int mtgv_encoder_set_param(mtgv_encoder* h, const char* key, const floa
 MTGV_API int mtgv_encoder_missing_params(const mtgv_encoder* h);
 /* x_dev: n images in `layout`; z_dev: (n, z_size) float32. */
 MTGV_API int mtgv_encoder_forward(mtgv_encoder* h, const void* x_dev, int32_t layout, int32_t n, float* z_dev, void* stream);
+/* mode 1: forwards of <= max_n images (default 16, 0 keeps it) replay a hipGraph captured per batch size;
+ * mode 0 (default): every launch eager.  Measured: no latency gain on this path - its ~90 short kernels are
+ * serialised by dependent-kernel boundaries, which a graph does not remove (profiles/README.md). */
+MTGV_API int mtgv_encoder_set_graph(mtgv_encoder* h, int32_t mode, int32_t max_n);
 /* keep a copy of every stage output of subsequent forwards (test/debug aid; off by default) */
 MTGV_API int mtgv_encoder_set_capture(mtgv_encoder* h, int32_t on);
 /* copy stage s (0..3) output of the last forward, NHWC (n, h, w, c), into out_dev; for tests */

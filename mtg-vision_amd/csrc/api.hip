@@ -71,6 +71,12 @@ MTGV_API int mtgv_encoder_forward(mtgv_encoder* h, const void* x_dev, int32_t la
     h->impl.forward(x_dev, layout, n, z_dev, (hipStream_t)stream);
   });
 }
+MTGV_API int mtgv_encoder_set_graph(mtgv_encoder* h, int32_t mode, int32_t max_n) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
+    h->impl.set_graph_mode(mode, max_n);
+  });
+}
 MTGV_API int mtgv_encoder_set_capture(mtgv_encoder* h, int32_t on) {
   return guarded([&] {
     MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");

@@ -77,6 +77,9 @@ class ParamStore {
 class Encoder {
  public:
   explicit Encoder(const mtgv_encoder_cfg& cfg);
+  ~Encoder();
+  // mode 0 (default): every launch issued eagerly; 1: batches of <= max_n images replay a captured hipGraph
+  void set_graph_mode(int mode, int max_n);
   void set_param(const char* key, const float* host, int64_t numel) {
     params_.set(key, host, numel);
     prepared_ = false;
@@ -108,6 +111,11 @@ class Encoder {
   std::vector<std::string> blk_prefix_[4];
   DevBuf folded_bias_;
   void prepare();
+  void body(int n, float* z_out, hipStream_t s);
+  int graph_mode_ = 0, graph_max_n_ = 16;
+  std::map<int, hipGraphExec_t> graphs_;
+  hipStream_t cap_stream_ = nullptr;
+  DevBuf zbuf_;
 };
 
 }  // namespace mtgv

@@ -324,6 +324,16 @@ void Encoder::prepare() {
   prepared_ = true;
 }
 
+Encoder::~Encoder() {
+  for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
+  if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
+}
+
+void Encoder::set_graph_mode(int mode, int max_n) {
+  graph_mode_ = mode;
+  if (max_n > 0) graph_max_n_ = max_n;
+}
+
 void Encoder::set_capture(bool on) {
   capture_ = on;
   if (on)
@@ -376,6 +386,42 @@ void Encoder::forward(const void* x, int layout, int n, float* z_out, hipStream_
   else
     MTGV_CHECK(false, ERR_INVALID, "unknown input layout %d", layout);
 
+  // Small batches are launch-bound (~90 launches of a few microseconds each): replay the whole body as one
+  // hipGraph.  The graph is captured per batch size after one eager pass (which performs every lazy
+  // initialisation), writes into an internal buffer, and the result is copied to the caller's tensor.
+  if (graph_mode_ != 0 && !capture_ && n <= graph_max_n_ && !gemm_profile_enabled()) {
+    zbuf_.ensure((size_t)cfg_.max_batch * cfg_.z_size);
+    auto it = graphs_.find(n);
+    if (it == graphs_.end()) {
+      body(n, zbuf_.p, s);  // eager warm-up, also a valid result
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      // capture on a private stream: the caller's stream may be the legacy default stream, which cannot capture
+      if (cap_stream_ == nullptr) HIP_OK(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
+      HIP_OK(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
+      try {
+        body(n, zbuf_.p, cap_stream_);
+      } catch (...) {
+        (void)hipStreamEndCapture(cap_stream_, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+      }
+      HIP_OK(hipStreamEndCapture(cap_stream_, &graph));
+      HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      it = graphs_.emplace(n, exec).first;
+    }
+    HIP_OK(hipGraphLaunch(it->second, s));
+    HIP_OK(hipMemcpyAsync(z_out, zbuf_.p, (size_t)n * cfg_.z_size * sizeof(float), hipMemcpyDeviceToDevice, s));
+    last_n_ = n;
+    return;
+  }
+  body(n, z_out, s);
+  last_n_ = n;
+}
+
+void Encoder::body(int n, float* z_out, hipStream_t s) {
+  const int H = cfg_.image_h, W = cfg_.image_w;
   const int* d = cfg_.dims;
   float* cur = xa_.p;
   float* alt = xb_.p;
@@ -459,7 +505,6 @@ void Encoder::forward(const void* x, int layout, int n, float* z_out, hipStream_
     GemmArgs g = linear_args(feat, feat_dim, head_w_, head_b_, z_out, zs, n, zs, feat_dim, ACT_NONE);
     gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
   }
-  last_n_ = n;
 }
 
 }  // namespace mtgv

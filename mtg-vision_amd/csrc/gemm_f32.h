@@ -79,6 +79,7 @@ void fold_shift_into_bias_launch(const float* W, const float* shift, const float
 
 // launch profiler for the roofline measurement (off by default; adds two event records per launch)
 void gemm_profile_enable(bool on);
+bool gemm_profile_enabled();
 void gemm_profile_read(double* ms, double* flops, long* launches);
 void gemm_profile_dump(const char* path);
 

@@ -469,6 +469,8 @@ void gemm_profile_dump(const char* path) {
   fclose(f);
 }
 
+bool gemm_profile_enabled() { return g_prof.on; }
+
 void gemm_profile_read(double* ms, double* flops, long* launches) {
   double total = 0;
   for (size_t i = 0; i + 1 < g_prof.used; i += 2) {

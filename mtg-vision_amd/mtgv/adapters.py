@@ -255,6 +255,8 @@ class CardSegmenter:
                 if len(pts) == 0:
                     continue
                 pts = (pts - np.asarray([left, top], np.float32)) / np.float32(ratio)  # scale_coords back to the frame
+                pts[:, 0] = np.clip(pts[:, 0], 0, rgb_im.shape[1])  # clip_coords
+                pts[:, 1] = np.clip(pts[:, 1], 0, rgb_im.shape[0])
                 detections.append(InstanceSeg(points=np.asarray(pts), label=0, conf=np.asarray(conf).tolist()))
         return detections
 

@@ -144,6 +144,10 @@ class Encoder:
     def ran_forward(self):
         return self.predict(np.random.rand(*self.input_hwc))
 
+    def set_graph(self, mode: int = 1, max_n: int = 0):
+        """mode 1: small batches (<= max_n images) replay a captured hipGraph; mode 0: eager launches only."""
+        native.check(native.lib().mtgv_encoder_set_graph(self._h, int(mode), int(max_n)))
+
     # ---- introspection ----------------------------------------------------------
     def set_capture(self, on: bool = True):
         native.check(native.lib().mtgv_encoder_set_capture(self._h, 1 if on else 0))

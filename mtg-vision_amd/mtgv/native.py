@@ -59,6 +59,7 @@ SIGNATURES = {
     "mtgv_encoder_set_param": (C.c_int, [c_vp, C.c_char_p, c_vp, c_i64]),
     "mtgv_encoder_missing_params": (C.c_int, [c_vp]),
     "mtgv_encoder_forward": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "mtgv_encoder_set_graph": (C.c_int, [c_vp, c_i32, c_i32]),
     "mtgv_encoder_set_capture": (C.c_int, [c_vp, c_i32]),
     "mtgv_encoder_stage_output": (C.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "mtgv_encoder_flops": (C.c_int, [c_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
