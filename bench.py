@@ -27,7 +27,10 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+# /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (f32-input; f16-input) and the HBM3E rate
+PEAK_MFMA_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
+MFMA_FLOPS_PER_FLOP = {"f32": 1, "f16x3": 3}  # f16x3 issues three fp16 MFMAs per algorithmic product
+PEAK_HBM_GBS = 8000.0
 
 
 def parse():
@@ -40,6 +43,7 @@ def parse():
     ap.add_argument("--encoder", default="cnvnxt2ae_tiny", help="cnvnxt2ae_tiny | cnvnxt2ae_nano | ...")
     ap.add_argument("--bank", type=int, default=100_000)
     ap.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3"], help="GEMM operand precision (default: library default / MTGV_GEMM_PREC)")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: detect(i) -> embed(i) strictly in sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -80,6 +84,9 @@ def main():
     from mtgv.matcher import Matcher, merge_topk
     from mtgv.pipeline import Pipeline
 
+    if a.precision:
+        native.set_gemm_precision(a.precision)
+    precision = native.get_gemm_precision()
     F, K = a.frames, a.cards
     det_cfg = spec.DetectorConfig()
     enc_cfg = spec.encoder_config(a.encoder, (192, 128), "conv+linear")
@@ -123,8 +130,10 @@ def main():
 
     # every step is one full pass over one batch; with overlap (default) the detect stage of step i+1 runs on a
     # second HIP stream beside the embed/match stages of step i - all K steps start and finish inside the timed region
+    overlap = (not a.no_overlap) and pipe.overlap_enabled()
+
     def run_steps(k):
-        if a.no_overlap:
+        if not overlap:
             return [pipe.run(frames) for _ in range(k)]
         return pipe.run_many([frames] * k)
 
@@ -152,7 +161,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": precision,
         "data": "synthetic",
         "config": {
             "workload": f"full pipeline per GPU: {F} frames 640x640x3 u8 -> YOLOv8n-seg(nc=3) detect+NMS+masks -> {K} cards/frame "
@@ -162,7 +171,9 @@ def main():
             "bank": [a.bank, 768],
             "bank_layout": ("row-sharded %d-way + RCCL all-gather of per-shard top-1" % world) if sharded else "replicated",
             "weights": "random-init (seeded), no trained weights offline",
-            "streams": "1" if a.no_overlap else "2 (detect of step i+1 beside embed+match of step i)",
+            "gemm_operands": "f32 operands, f32-input MFMA" if precision == "f32" else "f32 tensors in HBM; GEMM operands split on the fly "
+            "into fp16 hi+lo, 3 fp16 MFMAs per product, f32 accumulate (error vs fp64 at the f32 level, tests/test_gpu_precision.py)",
+            "streams": "2 (detect of step i+1 beside embed+match of step i)" if overlap else "1",
         },
     }
 
@@ -179,10 +190,11 @@ def main():
         for _ in range(nprof):
             pipe.run(frames)
         torch.cuda.synchronize()
-        ms, fl, nl = C.c_double(0), C.c_double(0), C.c_int64(0)
+        ms, fl, nl, by = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_double(0)
         native.check(L.mtgv_profile_gemm_read(C.byref(ms), C.byref(fl), C.byref(nl)))
+        native.check(L.mtgv_profile_gemm_bytes(C.byref(by)))
         native.check(L.mtgv_profile_gemm(0))
-        prof = (ms.value / nprof, fl.value / nprof, int(nl.value // nprof))
+        prof = (ms.value / nprof, fl.value / nprof, int(nl.value // nprof), by.value / nprof)
         barrier()
 
     if rank == 0:
@@ -190,27 +202,44 @@ def main():
         det_flops = detector.flops_per_frame()
         res["config"]["algorithmic_gflop_per_card"] = round((gflops_enc + dw_enc + det_flops / K + 2 * a.bank * 768) / 1e9, 3)
         if prof is not None:
-            gemm_ms, gemm_fl, launches = prof
-            ach = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            gemm_ms, gemm_fl, launches, gemm_bytes = prof
+            sec = gemm_ms * 1e-3
+            tfl = gemm_fl / sec / 1e12 if sec > 0 else 0.0
+            gbs = gemm_bytes / sec / 1e9 if sec > 0 else 0.0
+            peak_tf = PEAK_MFMA_TFLOPS[precision]
+            issued = tfl * MFMA_FLOPS_PER_FLOP[precision]
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")
             if os.path.exists(tfile):
                 try:
-                    traffic = json.load(open(tfile)).get("hbm_bytes_per_step")
+                    traffic = json.load(open(tfile)).get(precision, {}).get("hbm_bytes_per_step")
                 except Exception:
                     traffic = None
+            # which roof binds the kernel: the larger of its two minimum times
+            t_mfma = gemm_fl * MFMA_FLOPS_PER_FLOP[precision] / (peak_tf * 1e12)
+            t_hbm = gemm_bytes / (PEAK_HBM_GBS * 1e9)
+            mfma_view = {"achieved": round(tfl, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tfl / peak_tf, 4),
+                         "issued_mfma_tflops": round(issued, 2), "issued_frac": round(issued / peak_tf, 4)}
+            hbm_view = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+            bound = "mfma" if t_mfma >= t_hbm else "hbm"
+            top = mfma_view if bound == "mfma" else hbm_view
             res["roofline"] = {
-                "bound": "mfma",
-                "kernel": "gemm_f32_kernel (f32-input MFMA implicit GEMM; all launches of one step)",
-                "achieved": round(ach, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "bound": bound,
+                "kernel": "gemm_f32_kernel<..., PREC=%d> (implicit-GEMM conv/linear/bank kernel; all launches of one step)" % (0 if precision == "f32" else 1),
+                "achieved": top["achieved"],
+                "peak": top["peak"],
+                "unit": top["unit"],
+                "frac": top["frac"],
                 "traffic": traffic,
                 "traffic_note": "HBM bytes of these launches per step, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/gemm_traffic.json)",
                 "launches_per_step": launches,
                 "gemm_ms_per_step": round(gemm_ms, 3),
                 "algorithmic_gflop_per_step": round(gemm_fl / 1e9, 2),
+                "algorithmic_gbyte_per_step": round(gemm_bytes / 1e9, 3),
+                "min_ms_at_mfma_peak": round(t_mfma * 1e3, 3),
+                "min_ms_at_hbm_peak": round(t_hbm * 1e3, 3),
+                "mfma_view": mfma_view,
+                "hbm_view": hbm_view,
                 "measured": "HIP events around every launch on its stream, 2 single-stream passes after the timed region",
             }
         if world == 1 and not a.no_cpu_baseline:

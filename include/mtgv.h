@@ -40,11 +40,26 @@ MTGV_API int mtgv_version(void);
 /* number of HIP devices visible; does not initialise a device context */
 MTGV_API int mtgv_device_count(void);
 
-/* Measurement aid: when enabled, every launch of the f32-MFMA GEMM kernel is bracketed by HIP
+/* Operand precision of every GEMM-shaped kernel launch of the process (convs, linears, mask and bank GEMMs).
+ *   MTGV_PREC_F32   (0)  f32 operands on the f32-input matrix instruction (exact products).
+ *   MTGV_PREC_F16X3 (1)  each f32 operand split on the fly into fp16 hi + lo; three fp16 matrix instructions per
+ *                        product, f32 accumulate.  Error vs fp64 at the f32 level, ~2x the GEMM rate; operands
+ *                        must lie inside the fp16 range (|x| <= 65504), larger values turn into inf.
+ * The initial value comes from the environment (MTGV_GEMM_PREC=f32|f16x3, default f16x3).  Both
+ * meet the path's 1e-4 contract against the reference (tests/test_gpu_precision.py).  Not thread-safe: set it
+ * before the worker threads start. */
+#define MTGV_PREC_F32 0
+#define MTGV_PREC_F16X3 1
+MTGV_API int mtgv_set_gemm_precision(int32_t prec);
+MTGV_API int mtgv_get_gemm_precision(int32_t* prec);
+
+/* Measurement aid: when enabled, every launch of the GEMM kernel is bracketed by HIP
  * events on its own stream.  _read waits for them and returns the summed kernel time (ms), the
  * summed algorithmic FLOPs (2*M*N*K of the unpadded problems) and the launch count since enable. */
 MTGV_API int mtgv_profile_gemm(int32_t enable);
 MTGV_API int mtgv_profile_gemm_read(double* total_ms, double* total_flops, int64_t* launches);
+/* compulsory HBM bytes of the launches since enable: every operand element read once, every result written once */
+MTGV_API int mtgv_profile_gemm_bytes(double* total_bytes);
 /* write one CSV row per recorded launch (shape, tile, ms, TFLOP/s) */
 MTGV_API int mtgv_profile_gemm_dump(const char* csv_path);
 

@@ -31,6 +31,17 @@ MTGV_API int mtgv_device_count(void) {
   return n;
 }
 
+// ---- GEMM operand precision ----
+MTGV_API int mtgv_set_gemm_precision(int32_t prec) {
+  return guarded([&] { gemm_set_precision(prec); });
+}
+MTGV_API int mtgv_get_gemm_precision(int32_t* prec) {
+  return guarded([&] {
+    MTGV_CHECK(prec != nullptr, ERR_INVALID, "null output");
+    *prec = gemm_precision();
+  });
+}
+
 // ---- GEMM launch profiler ----
 MTGV_API int mtgv_profile_gemm(int32_t enable) {
   return guarded([&] { gemm_profile_enable(enable != 0); });
@@ -40,6 +51,13 @@ MTGV_API int mtgv_profile_gemm_read(double* total_ms, double* total_flops, int64
     long l = 0;
     gemm_profile_read(total_ms, total_flops, &l);
     if (launches) *launches = l;
+  });
+}
+
+MTGV_API int mtgv_profile_gemm_bytes(double* total_bytes) {
+  return guarded([&] {
+    MTGV_CHECK(total_bytes != nullptr, ERR_INVALID, "null output");
+    *total_bytes = gemm_profile_bytes();
   });
 }
 

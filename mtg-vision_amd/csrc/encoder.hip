@@ -8,6 +8,7 @@
 //   GRN finalize               -> scale[n][4C]  grn_finalize_kernel
 //   (hid*scale + beta) @ W2^T + b2 + residual -> out      gemm_f32 (A prologue + epilogue)
 #include "encoder.h"
+#include <stdlib.h>
 #include "rowops.h"
 
 #include <string.h>
@@ -391,7 +392,8 @@ void Encoder::forward(const void* x, int layout, int n, float* z_out, hipStream_
   // initialisation), writes into an internal buffer, and the result is copied to the caller's tensor.
   if (graph_mode_ != 0 && !capture_ && n <= graph_max_n_ && !gemm_profile_enabled()) {
     zbuf_.ensure((size_t)cfg_.max_batch * cfg_.z_size);
-    auto it = graphs_.find(n);
+    const int gkey = n * 2 + gemm_precision();  // a captured graph holds the kernels of one operand precision
+    auto it = graphs_.find(gkey);
     if (it == graphs_.end()) {
       body(n, zbuf_.p, s);  // eager warm-up, also a valid result
       hipGraph_t graph = nullptr;
@@ -409,7 +411,7 @@ void Encoder::forward(const void* x, int layout, int n, float* z_out, hipStream_
       HIP_OK(hipStreamEndCapture(cap_stream_, &graph));
       HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
-      it = graphs_.emplace(n, exec).first;
+      it = graphs_.emplace(gkey, exec).first;
     }
     HIP_OK(hipGraphLaunch(it->second, s));
     HIP_OK(hipMemcpyAsync(z_out, zbuf_.p, (size_t)n * cfg_.z_size * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -74,6 +74,12 @@ GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue = false, bool scaled
 int gemm_grn_segmax(const GemmPlan& p, int hw);
 size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw);
 void gemm_launch(const GemmArgs& a, const GemmPlan& p, hipStream_t s);
+
+// Operand precision of every GEMM launch of the process (see gemm_f32.hip): GEMM_PREC_F32 = f32 MFMA,
+// GEMM_PREC_F16X3 = fp16 hi+lo split, three fp16 MFMAs per product.  Initial value from MTGV_GEMM_PREC=f32|f16x3.
+enum { GEMM_PREC_F32 = 0, GEMM_PREC_F16X3 = 1 };
+int gemm_precision();
+void gemm_set_precision(int prec);
 // out[n] = bias[n] + W[n][:] . shift  (GRN beta folded into the next Linear's bias; a_shift is not applied by the GEMM)
 void fold_shift_into_bias_launch(const float* W, const float* shift, const float* bias, float* out, int N, int K, hipStream_t s);
 
@@ -82,6 +88,7 @@ void gemm_profile_enable(bool on);
 bool gemm_profile_enabled();
 void gemm_profile_read(double* ms, double* flops, long* launches);
 void gemm_profile_dump(const char* path);
+double gemm_profile_bytes();  // compulsory operand + result bytes of the launches recorded since enable
 
 // sum the partials of one GEMM into the GRN apply table
 //   scale[img][n] = gamma[n] * Gx / (mean_n Gx + 1e-6) + 1,  Gx = sqrt(sum x^2)

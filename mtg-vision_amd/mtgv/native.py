@@ -51,8 +51,11 @@ SIGNATURES = {
     "mtgv_last_error": (C.c_char_p, []),
     "mtgv_version": (C.c_int, []),
     "mtgv_device_count": (C.c_int, []),
+    "mtgv_set_gemm_precision": (C.c_int, [c_i32]),
+    "mtgv_get_gemm_precision": (C.c_int, [C.POINTER(c_i32)]),
     "mtgv_profile_gemm": (C.c_int, [c_i32]),
     "mtgv_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64)]),
+    "mtgv_profile_gemm_bytes": (C.c_int, [C.POINTER(C.c_double)]),
     "mtgv_profile_gemm_dump": (C.c_int, [C.c_char_p]),
     "mtgv_encoder_create": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(c_vp)]),
     "mtgv_encoder_destroy": (None, [c_vp]),
@@ -148,3 +151,19 @@ def stream() -> c_vp:
 def require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError("mtgv: no HIP device visible - the recognition path runs only on the GPU (no CPU fallback)")
+
+
+PRECISIONS = {"f32": 0, "f16x3": 1}
+
+
+def set_gemm_precision(name: str) -> None:
+    """'f32' (f32-input MFMA) or 'f16x3' (fp16 hi+lo split, three fp16 MFMAs per product) for every GEMM launch."""
+    if name not in PRECISIONS:
+        raise AssertionError(f"precision {name!r}: expected one of {sorted(PRECISIONS)}")
+    check(lib().mtgv_set_gemm_precision(PRECISIONS[name]))
+
+
+def get_gemm_precision() -> str:
+    v = c_i32(0)
+    check(lib().mtgv_get_gemm_precision(C.byref(v)))
+    return {n: k for k, n in PRECISIONS.items()}[v.value]

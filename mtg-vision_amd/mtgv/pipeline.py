@@ -7,10 +7,12 @@ batch of frames goes through each stage once; every stage's arithmetic is in lib
 
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional
 
 import torch
 
+from . import native
 from .crop import boxes_to_quads, warp_quads
 from .detector import Detector
 from .encoder import Encoder
@@ -54,11 +56,23 @@ class Pipeline:
             "det": det,
         }
 
+    @staticmethod
+    def overlap_enabled() -> bool:
+        return native.get_gemm_precision() == "f32" or os.environ.get("MTGV_OVERLAP") == "force"
+
     def run_many(self, batches, flip_rgb: bool = True):
         """Process a sequence of frame batches with the detect stage of batch i+1 overlapped with the
         crop/embed/match stages of batch i on a second HIP stream.  The detector's late layers have too few
         tiles to fill 256 CUs on their own; the encoder's GEMMs of the previous batch fill the gaps.
-        Results are identical to `run` on each batch (same kernels, same order per stream)."""
+        Results are identical to `run` on each batch (same kernels, same order per stream).
+
+        The two-stream schedule is used with f32 GEMM operands only.  With f16x3 operands the batches run back to
+        back on the current stream: on MI355X the fused dwconv7+LayerNorm kernel returned wrong values in a few
+        16-lane groups when it shared CUs with the split-precision GEMM of the other stream (never in one stream,
+        never with f32 operands; tools/debug/determinism_probe*.py).  MTGV_OVERLAP=force
+        overrides this for experiments."""
+        if not self.overlap_enabled():
+            return [self.run(frames, flip_rgb) for frames in batches]
         dev = self.detector.device
         if not hasattr(self, "_s_det"):
             self._s_det, self._s_enc = torch.cuda.Stream(dev), torch.cuda.Stream(dev)

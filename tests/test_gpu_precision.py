@@ -1,0 +1,130 @@
+"""Both GEMM operand precisions (f32 MFMA, fp16 hi+lo split "f16x3") meet the path's contract.
+
+The rest of the GPU suite runs under the library default; this module switches the precision through the
+C ABI and repeats the parity checks that involve GEMMs in BOTH modes: encoder embeddings vs the golden vectors of
+the reference (1e-4), a linear against fp64, identical top-1 ids, detector heads.
+"""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # BASELINE.json north_star: fp32 embeddings within 1e-4 of the PyTorch CPU path
+MODES = ["f32", "f16x3"]
+
+
+@pytest.fixture(autouse=True)
+def _restore_precision():
+    from mtgv import native
+
+    before = native.get_gemm_precision()
+    yield
+    native.set_gemm_precision(before)
+
+
+def test_precision_api():
+    from mtgv import native
+
+    for m in MODES:
+        native.set_gemm_precision(m)
+        assert native.get_gemm_precision() == m
+    with pytest.raises(AssertionError):
+        native.set_gemm_precision("bf16")
+    with pytest.raises(AssertionError):
+        native.check(native.lib().mtgv_set_gemm_precision(7))
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["ae_nano_192x128", "ae_tiny_192x128", "plain_tiny_224"])
+def test_encoder_golden(mode, name):
+    from mtgv import native, spec
+    from mtgv.encoder import Encoder
+
+    native.set_gemm_precision(mode)
+    g = np.load(os.path.join(GOLDEN, f"encoder_{name}.npz"))
+    d = ast.literal_eval(str(g["cfg"]))
+    cfg = spec.EncoderConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items()})
+    enc = Encoder(cfg, spec.random_encoder_state(cfg, 1), max_batch=4)
+    x = np.random.default_rng(0).random((4, 3, *cfg.image_hw), dtype=np.float32)
+    z = enc.encode(torch.from_numpy(x)).cpu().numpy()
+    e64 = np.abs(z - g["z_fp64"]).max()
+    print(f"{mode} {name}: max|z - ref_fp64| = {e64:.3e}")
+    assert e64 < TOL and np.abs(z - g["z_fp32"]).max() < TOL
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_linear_error_level(mode):
+    """error vs fp64 of one long-K product: the split path is as good as the exact-f32 chain, incl. operands that
+    are fp16-subnormal (1e-6) or large (1e3) next to ordinary ones"""
+    from mtgv import native as nv
+
+    nv.set_gemm_precision(mode)
+    m, n, k = 384, 320, 3072
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    a[:, ::7] *= 1e-6
+    a[:, 3::11] *= 1e3
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    A, W, B = (torch.from_numpy(t).cuda() for t in (a, w, b))
+    out = torch.empty((m, n), device="cuda")
+    nv.check(nv.lib().mtgv_op_linear(nv.ptr(A), nv.ptr(W), nv.ptr(B), None, nv.ptr(out), m, n, k, 0, nv.stream()))
+    ref = F.linear(torch.from_numpy(a).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double())
+    scale = ref.abs().max().item()
+    err = (out.cpu().double() - ref).abs().max().item() / scale
+    cpu32 = (F.linear(torch.from_numpy(a), torch.from_numpy(w), torch.from_numpy(b)).double() - ref).abs().max().item() / scale
+    print(f"{mode}: rel err {err:.2e} (PyTorch CPU fp32: {cpu32:.2e})")
+    assert err < 5e-6  # the f32 mode is one k-ordered fma chain over K = 3072
+
+
+def test_modes_agree_on_top1_and_scores():
+    from mtgv import native
+    from mtgv.matcher import Matcher
+    from oracle import match_ref
+
+    rng = np.random.default_rng(11)
+    bank = rng.standard_normal((20_000, 768)).astype(np.float32)
+    q = rng.standard_normal((64, 768)).astype(np.float32)
+    q[:8] = bank[100:108] + 0.01 * rng.standard_normal((8, 768)).astype(np.float32)
+    out = {}
+    for mode in MODES:
+        native.set_gemm_precision(mode)
+        m = Matcher(768, capacity=len(bank))
+        m.add(bank)
+        i, s = m.match(torch.from_numpy(q).cuda(), 5)
+        out[mode] = (s.cpu().numpy(), i.cpu().numpy())
+    ri, rs = match_ref.cosine_topk(q, bank, 5)
+    for mode in MODES:
+        s, i = out[mode]
+        assert np.abs(s - rs).max() < 2e-6
+        gap_ok = np.abs(np.diff(rs, axis=1)).min(axis=1) > 1e-5  # rows without near-ties must agree exactly
+        np.testing.assert_array_equal(i[gap_ok], ri[gap_ok])
+        np.testing.assert_array_equal(i[:8, 0], np.arange(100, 108))
+    assert gap_ok.sum() > 48
+
+
+def test_detector_heads_agree_between_modes():
+    from mtgv import native, spec
+    from mtgv.detector import Detector
+
+    cfg = spec.DetectorConfig()
+    sd = spec.random_detector_state(cfg, 3)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    frames = torch.randint(0, 256, (2, 640, 640, 3), generator=g, device="cuda", dtype=torch.uint8)
+    outs = {}
+    for mode in MODES:
+        native.set_gemm_precision(mode)
+        det = Detector(cfg, sd, max_batch=2)
+        det.forward(frames)
+        pred, protos = det.raw_outputs(2)
+        outs[mode] = (pred.cpu().double(), protos.cpu().double())
+    for a, b in zip(outs["f32"], outs["f16x3"]):
+        assert torch.isfinite(b).all()
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
