@@ -8,26 +8,40 @@ namespace mtgv {
 // epilogues evaluate one activation per output element; with the library expf and an IEEE divide the
 // K = 96 / 192 pointwise layers were VALU-bound, not MFMA-bound.  Relative error of the activations
 // below stays under ~1e-6, well inside the 1e-4 embedding tolerance (tests/test_gpu_encoder.py).
+//
+// Every function below starts with "fp contract(off)": whether a*b+c fuses must not depend on the template
+// instantiation a call is inlined into - a frame's detections are bit-identical alone or inside a batch, although
+// the two cases pick different GEMM tiles (tests/test_gpu_fullsize.py).
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
 
 // nn.GELU() erf form - mtgvision/models/convnextv2.py:192-193
-__device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float act_gelu(float x) {
+#pragma clang fp contract(off)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
 
 // nn.Mish = x * tanh(softplus(x)), softplus threshold 20 - mtgvision/models/convnextv2ae.py:17-18
 // Evaluated as x * n / (n + 2) with n = e^x (e^x + 2): tanh(log(1 + e^x)) = ((1+e^x)^2 - 1) / ((1+e^x)^2 + 1)
 // exactly, so one exp and one reciprocal replace exp + log1p + tanh; no cancellation anywhere, same
 // 20.0 cut-over as torch's softplus.
 __device__ __forceinline__ float act_mish(float x) {
+#pragma clang fp contract(off)
   const float e = fast_exp(fminf(x, 20.0f));
   const float n = e * (e + 2.0f);
   return x > 20.0f ? x : x * n * fast_rcp(n + 2.0f);
 }
 
 // SiLU of the YOLO Conv block (ultralytics Conv.default_act; call site od_export.py:150)
-__device__ __forceinline__ float act_silu(float x) { return x * fast_rcp(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float act_silu(float x) {
+#pragma clang fp contract(off)
+  return x * fast_rcp(1.0f + fast_exp(-x));
+}
 
-__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float act_sigmoid(float x) {
+#pragma clang fp contract(off)
+  return 1.0f / (1.0f + expf(-x));
+}
 
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {

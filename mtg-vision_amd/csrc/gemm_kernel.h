@@ -44,6 +44,7 @@ constexpr size_t gemm_lds_bytes(int nseg_max) {
 
 template <int TM, int TN, int BK, bool CONV, bool APRO, int EPI, int ACT, int PREC>
 __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN == 2 ? (BK == 16 ? 5 : 4) : TM * TN == 3 ? (BK == 16 ? 4 : 3) : TM * TN == 4 ? (BK == 16 ? 3 : 2) : 2)) void gemm_f32_kernel(const GemmDev g) {
+#pragma clang fp contract(off)  // loader scaling and epilogue arithmetic identical in every instantiation (act.h)
   constexpr int BM = 128 * TM, BN = 32 * TN, LS = BK + 4;
   constexpr int LSH = BK == 16 ? 16 : BK + 8;  // PREC 1: halves per staged row
   constexpr int KQ = BK / 4;      // float4 per staged row

@@ -12,7 +12,6 @@ from typing import Callable, Optional
 
 import torch
 
-from . import native
 from .crop import boxes_to_quads, warp_quads
 from .detector import Detector
 from .encoder import Encoder
@@ -58,7 +57,7 @@ class Pipeline:
 
     @staticmethod
     def overlap_enabled() -> bool:
-        return native.get_gemm_precision() == "f32" or os.environ.get("MTGV_OVERLAP") == "force"
+        return os.environ.get("MTGV_OVERLAP", "on") != "off"
 
     def run_many(self, batches, flip_rgb: bool = True):
         """Process a sequence of frame batches with the detect stage of batch i+1 overlapped with the
@@ -66,11 +65,10 @@ class Pipeline:
         tiles to fill 256 CUs on their own; the encoder's GEMMs of the previous batch fill the gaps.
         Results are identical to `run` on each batch (same kernels, same order per stream).
 
-        The two-stream schedule is used with f32 GEMM operands only.  With f16x3 operands the batches run back to
-        back on the current stream: on MI355X the fused dwconv7+LayerNorm kernel returned wrong values in a few
-        16-lane groups when it shared CUs with the split-precision GEMM of the other stream (never in one stream,
-        never with f32 operands; tools/debug/determinism_probe*.py).  MTGV_OVERLAP=force
-        overrides this for experiments."""
+        MTGV_OVERLAP=off keeps everything on the current stream.  (History: with packed-FP32 VALU instructions in
+        the library, kernels sharing a CU with the split-precision GEMM of the other stream sporadically lost a
+        packed result in one 16-lane group; the library is built without those instructions - build.py, DESIGN.md
+        section 5 - and tests/test_gpu_overlap.py guards the combination.)"""
         if not self.overlap_enabled():
             return [self.run(frames, flip_rgb) for frames in batches]
         dev = self.detector.device
