@@ -47,7 +47,10 @@ MTGV_API int mtgv_device_count(void);
  *                        must lie inside the fp16 range (|x| <= 65504), larger values turn into inf.
  * The initial value comes from the environment (MTGV_GEMM_PREC=f32|f16x3, default f16x3).  Both
  * meet the path's 1e-4 contract against the reference (tests/test_gpu_precision.py).  Not thread-safe: set it
- * before the worker threads start. */
+ * before the worker threads start.
+ * Note for F16X3 (measured on MI355X / ROCm 7.2): kernels of OTHER code that use packed-FP32
+ * arithmetic (v_pk_mul_f32, v_pk_fma_f32) and run on another stream of the same GPU at the same time can get wrong
+ * lanes; this library itself is built without those instructions.  Use F32 when foreign kernels share the GPU. */
 #define MTGV_PREC_F32 0
 #define MTGV_PREC_F16X3 1
 MTGV_API int mtgv_set_gemm_precision(int32_t prec);

@@ -130,7 +130,7 @@ GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue, bool scaled_a) {
   GemmPlan pl;
   if (const char* e = getenv("MTGV_GEMM_TILE")) {
     int tm = 0, tn = 0, bk = 0;
-    if (sscanf(e, "%d,%d,%d", &tm, &tn, &bk) == 3 && (tm == 1 || (tm == 2 && tn == 2)) && tn >= 1 && tn <= 5 &&
+    if (sscanf(e, "%d,%d,%d", &tm, &tn, &bk) == 3 && (tm == 1 || tm == 2) && tn >= 1 && tn <= 5 &&
         (bk == 16 || bk == 32)) {
       pl.tm = tm, pl.tn = tn, pl.bk = bk;
       pl.tiles_m = ceil_div(M, pl.bm());

@@ -552,7 +552,8 @@ static bool gemm_dispatch(const GemmDev& g, const GemmPlan& pl, bool conv, bool 
   }
   MTGV_CASE(1, 1, 16) MTGV_CASE(1, 2, 16) MTGV_CASE(1, 3, 16) MTGV_CASE(1, 4, 16) MTGV_CASE(1, 5, 16) MTGV_CASE(1, 1, 32)
 #ifdef MTGV_ALL_TILES  // sweep-only shapes (tools/gemm_sweep.py); never chosen by gemm_plan
-  MTGV_CASE(1, 2, 32) MTGV_CASE(1, 3, 32) MTGV_CASE(1, 4, 32) MTGV_CASE(2, 2, 16) MTGV_CASE(2, 2, 32)
+  MTGV_CASE(1, 2, 32) MTGV_CASE(1, 3, 32) MTGV_CASE(1, 4, 32) MTGV_CASE(2, 2, 16) MTGV_CASE(2, 2, 32) MTGV_CASE(2, 1, 16)
+  MTGV_CASE(2, 3, 16) MTGV_CASE(2, 4, 16) MTGV_CASE(2, 3, 32)
 #endif
 #undef MTGV_CASE
   return false;

@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtgv.so")
+LIB_PATH = os.environ.get("MTGV_LIB_PATH", os.path.join(_HERE, "libmtgv.so"))  # override: experiments with alternative builds
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 c_fp = C.POINTER(C.c_float)

@@ -32,7 +32,7 @@ if which in ("enc", "all"):
     shapes += [(256, 100000, 768, 0)]
 if which in ("det", "all"):
     shapes += [(819200, 32, 32, 3), (204800, 64, 64, 3), (51200, 128, 256, 3), (12800, 256, 384, 3), (204800, 64, 192, 3)]
-tiles = [None] + [(1, tn, bk) for tn in (1, 2, 3, 4, 5) for bk in (16, 32) if not (tn == 5 and bk == 32)] + [(2, 2, 16), (2, 2, 32)]
+tiles = [None] + [(1, tn, bk) for tn in (1, 2, 3, 4, 5) for bk in (16, 32) if not (tn == 5 and bk == 32)] + [(2, 1, 16), (2, 2, 16), (2, 3, 16), (2, 4, 16), (2, 2, 32), (2, 3, 32)]
 for (m, n, k, act) in shapes:
     res = []
     for t in tiles:
