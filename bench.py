@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--encoder", default="cnvnxt2ae_tiny", help="cnvnxt2ae_tiny | cnvnxt2ae_nano | ...")
     ap.add_argument("--bank", type=int, default=100_000)
     ap.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
+    ap.add_argument("--quads", default="box", choices=["box", "mask"], help="crop the detection boxes (default, SURVEY 8d config 4) or the "
+                    "oriented quads fitted to the detection masks on the GPU")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"], help="GEMM operand precision (default: library default / MTGV_GEMM_PREC)")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: detect(i) -> embed(i) strictly in sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -118,7 +120,7 @@ def main():
                 return mdist.sharded_topk(z.cpu(), k, loc, mrg)
     else:
         match_fn = None
-    pipe = Pipeline(detector, encoder, matcher, K, 1, match_fn)
+    pipe = Pipeline(detector, encoder, matcher, K, 1, match_fn, quad_source=a.quads)
 
     g = torch.Generator(device=dev).manual_seed(4 + rank)
     frames = torch.randint(0, 256, (F, 640, 640, 3), generator=g, device=dev, dtype=torch.uint8)
@@ -166,6 +168,7 @@ def main():
         "config": {
             "workload": f"full pipeline per GPU: {F} frames 640x640x3 u8 -> YOLOv8n-seg(nc=3) detect+NMS+masks -> {K} cards/frame "
             f"-> 192x128 crops -> ConvNeXt-V2 {a.encoder} (z=768) -> cosine top-1 over {a.bank}x768 bank",
+            "crop_quads": "detection boxes" if a.quads == "box" else "oriented quads fitted to the detection masks (mask_quads_kernel)",
             "frames_per_gpu": F,
             "cards_per_frame": K,
             "bank": [a.bank, 768],

@@ -192,6 +192,19 @@ MTGV_API int mtgv_nms(const float* pred_dev, int32_t n, int32_t nc, int32_t nm, 
 MTGV_API size_t mtgv_nms_workspace_bytes(int32_t n, int32_t na);
 
 /* ------------------------------------------------------------------------- */
+/* Mask -> oriented card quad.                                                */
+/* Replaces the host geometry of InstanceSeg._orient                          */
+/* (mtgvision/od_export.py:52-93: close the U-shaped mask, four corners,      */
+/* corner 0 = the card's top-left).                                           */
+/* ------------------------------------------------------------------------- */
+/* masks_dev (n, h, w) uint8, non-zero = foreground (mtgv_mask_binarize output); boxes_dev (n, 4) xyxy float32 or NULL:
+ * the quad reported for an empty mask.  quads_dev (n, 4, 2) float32 corners (x, y) in pixels of the mask grid, ordered
+ * top-left, top-right, bottom-right, bottom-left of the card; ok_dev (n) int32: 1 = from the mask, 0 = empty mask.
+ * The quad is the minimum-area rectangle of the mask's convex hull; "up" is mask centroid minus hull centroid. */
+MTGV_API int mtgv_mask_quads(const uint8_t* masks_dev, int32_t n, int32_t h, int32_t w, const float* boxes_dev, float* quads_dev,
+                             int32_t* ok_dev, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Crop: perspective de-warp of card quads.                                   */
 /* Replaces InstanceSeg.extract_dewarped (mtgvision/od_export.py:95-111).     */
 /* ------------------------------------------------------------------------- */

@@ -39,3 +39,25 @@ def boxes_to_quads(boxes_xyxy: torch.Tensor) -> torch.Tensor:
     """(n, 4) xyxy -> (n, 4, 2) corners in the order extract_dewarped matches to [[0,0],[w,0],[w,h],[0,h]]."""
     x1, y1, x2, y2 = boxes_xyxy.unbind(-1)
     return torch.stack([torch.stack([x1, y1], -1), torch.stack([x2, y1], -1), torch.stack([x2, y2], -1), torch.stack([x1, y2], -1)], -2)
+
+
+def mask_quads(masks_u8: torch.Tensor, boxes_xyxy: torch.Tensor = None):
+    """masks (n, H, W) uint8 on the GPU (non-zero = card) -> (quads (n, 4, 2) float32, ok (n,) int32).
+
+    The quad is the minimum-area rectangle around the mask with corner 0 at the card's top-left - the GPU form of
+    `InstanceSeg._orient` (mtgvision/od_export.py:52-93).  Rows with an empty mask get `boxes_xyxy` (or zeros) and
+    ok = 0."""
+    native.require_gpu()
+    assert masks_u8.is_cuda and masks_u8.dtype == torch.uint8 and masks_u8.ndim == 3, f"{tuple(masks_u8.shape)} {masks_u8.dtype}"
+    n, h, w = masks_u8.shape
+    quads = torch.zeros((n, 4, 2), dtype=torch.float32, device=masks_u8.device)
+    ok = torch.zeros((n,), dtype=torch.int32, device=masks_u8.device)
+    if n == 0:
+        return quads, ok
+    if boxes_xyxy is not None:
+        boxes_xyxy = boxes_xyxy.to(masks_u8.device, torch.float32).contiguous()
+        assert tuple(boxes_xyxy.shape) == (n, 4), f"{tuple(boxes_xyxy.shape)}"
+    with torch.cuda.device(masks_u8.device):
+        native.check(native.lib().mtgv_mask_quads(native.ptr(masks_u8.contiguous()), n, h, w, native.ptr(boxes_xyxy), native.ptr(quads),
+                                                  native.ptr(ok), native.stream()))
+    return quads, ok

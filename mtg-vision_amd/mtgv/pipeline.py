@@ -12,8 +12,8 @@ from typing import Callable, Optional
 
 import torch
 
-from .crop import boxes_to_quads, warp_quads
-from .detector import Detector
+from .crop import boxes_to_quads, mask_quads, warp_quads
+from .detector import Detector, binarize_masks
 from .encoder import Encoder
 from .matcher import Matcher
 
@@ -27,7 +27,12 @@ _PAD_BOXES = torch.tensor(
 
 class Pipeline:
     def __init__(self, detector: Detector, encoder: Encoder, matcher, cards_per_frame: int = 8, top_k: int = 1,
-                 match_fn: Optional[Callable] = None):
+                 match_fn: Optional[Callable] = None, quad_source: str = "box"):
+        """quad_source: "box" crops the detection boxes (the synthetic bench workload, SURVEY.md section 8d config 4);
+        "mask" crops the oriented quad fitted to each detection's mask, as the reference does
+        (od_export.py:52-111: InstanceSeg._orient + extract_dewarped)."""
+        assert quad_source in ("box", "mask"), quad_source
+        self.quad_source = quad_source
         self.detector, self.encoder, self.matcher = detector, encoder, matcher
         self.K = int(cards_per_frame)
         self.top_k = int(top_k)
@@ -41,6 +46,12 @@ class Pipeline:
         have = torch.arange(K, device=frames_u8.device)[None, :] < det["n_det"][:, None]
         boxes = torch.where(have[..., None], det["boxes"][:, :K], self._pad[None].expand(F, K, 4))
         quads = boxes_to_quads(boxes.reshape(F * K, 4))
+        if self.quad_source == "mask":
+            # masks of the K best detections (logits are zero outside a detection's box), at frame resolution
+            masks = binarize_masks(det["mask_logits"][:, :K].reshape(F * K, *det["mask_logits"].shape[-2:]))
+            mq, ok = mask_quads(masks, boxes.reshape(F * K, 4))
+            use = (ok.view(F, K) > 0) & have  # no detection / empty mask: keep the box (or pad) quad
+            quads = torch.where(use.reshape(F * K, 1, 1), mq, quads)
         frame_idx = torch.arange(F, device=frames_u8.device, dtype=torch.int32).repeat_interleave(K)
         crops = warp_quads(frames_u8, quads, frame_idx, self.encoder.cfg.image_hw, 0.05)
         z = self.encoder.encode(crops)

@@ -37,16 +37,18 @@ def select_boxes(dets, K):
     return np.stack(out)
 
 
-def run(det_params, det_cfg, enc_params, enc_cfg, bank, frames_u8, K=8, top_k=1, flip_rgb=True, boxes=None):
+def run(det_params, det_cfg, enc_params, enc_cfg, bank, frames_u8, K=8, top_k=1, flip_rgb=True, boxes=None, quads=None):
     """-> dict(ids (F,K,top_k), scores, boxes (F,K,4), crops (F*K,h,w,3) u8, z (F*K, z))
 
-    `boxes` may be supplied (e.g. the GPU detector's) to check the later stages on identical inputs."""
+    `boxes` (and `quads` (F*K,4,2), e.g. from quad_ref.mask_quads) may be supplied to check the later stages on
+    identical inputs."""
     F = frames_u8.shape[0]
     dets = None
     if boxes is None:
         dets, _, _ = detector_ref.detect(det_params, det_cfg, frames_u8, flip_rgb)
         boxes = select_boxes(dets, K)
-    quads = boxes_to_quads(boxes.reshape(F * K, 4))
+    if quads is None:
+        quads = boxes_to_quads(boxes.reshape(F * K, 4))
     h, w = enc_cfg.image_hw
     crops = np.stack([warp_ref.warp_quad(frames_u8[i // K], quads[i], (h, w), 0.05) for i in range(F * K)])
     x = encoder_ref.img_float32(crops).transpose(0, 3, 1, 2)

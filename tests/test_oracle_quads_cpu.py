@@ -1,0 +1,76 @@
+"""CPU checks of the mask -> quad oracle (oracle/quad_ref.py): known rectangles, U-shaped masks, degenerate masks,
+and agreement with the host statement in mtgv/adapters.py (InstanceSeg._orient) on single-blob masks."""
+import numpy as np
+import pytest
+
+from oracle import quad_ref as Q
+
+
+def _rot_rect_mask(h, w, cx, cy, rw, rh, ang_deg, notch=0.0):
+    """filled rotated rectangle; `notch` > 0 removes a centred bite from its bottom edge (the U shape of a held card)"""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    t = np.deg2rad(ang_deg)
+    u = (xx - cx) * np.cos(t) + (yy - cy) * np.sin(t)  # along the card's width
+    v = -(xx - cx) * np.sin(t) + (yy - cy) * np.cos(t)  # along the card's height (down)
+    m = (np.abs(u) <= rw / 2) & (np.abs(v) <= rh / 2)
+    if notch > 0:
+        m &= ~((np.abs(u) <= rw * 0.3) & (v > rh / 2 - notch * rh))
+    corners = np.asarray([[-rw / 2, -rh / 2], [rw / 2, -rh / 2], [rw / 2, rh / 2], [-rw / 2, rh / 2]])
+    R = np.asarray([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+    return m, corners @ R.T + np.asarray([cx, cy])
+
+
+@pytest.mark.parametrize("ang", [0, 17, 45, 90, 133, 180, 212, 270, 301])
+def test_u_shape_gives_oriented_rectangle(ang):
+    m, want = _rot_rect_mask(200, 240, 120, 100, 70, 100, ang, notch=0.35)
+    q, ok = Q.mask_quad(m)
+    assert ok == 1
+    assert np.abs(q - want).max() < 2.0, f"{q} vs {want}"  # corner 0 = top-left of the card, clockwise
+
+
+def test_degenerate_masks():
+    m = np.zeros((32, 48), bool)
+    q, ok = Q.mask_quad(m, box=[1, 2, 30, 20])
+    assert ok == 0 and q.tolist() == [[1, 2], [30, 2], [30, 20], [1, 20]]
+    assert Q.mask_quad(m)[1] == 0
+    m[5, 7] = True
+    q, ok = Q.mask_quad(m)
+    assert ok == 1 and (q == np.asarray([7, 5], np.float32)).all()
+    m[5, 7:20] = True  # one row of pixels
+    q, ok = Q.mask_quad(m)
+    assert ok == 1 and sorted(map(tuple, q.tolist())) == [(7.0, 5.0), (7.0, 5.0), (19.0, 5.0), (19.0, 5.0)]
+    d = np.eye(24, dtype=bool)  # a diagonal: collinear points, hull of two vertices
+    q, ok = Q.mask_quad(d)
+    assert ok == 1 and q.min() == 0 and q.max() == 23
+    full = np.ones((16, 20), bool)
+    q, ok = Q.mask_quad(full)
+    assert ok == 1 and sorted(map(tuple, q.tolist())) == [(0.0, 0.0), (0.0, 15.0), (19.0, 0.0), (19.0, 15.0)]
+
+
+def test_hull_matches_scipy_on_random_blobs():
+    from scipy.spatial import ConvexHull
+
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        m = np.zeros((60, 80), bool)
+        for _ in range(4):
+            cy, cx, r = rng.integers(10, 50), rng.integers(10, 70), rng.integers(3, 12)
+            yy, xx = np.mgrid[0:60, 0:80]
+            m |= (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+        ys, xmin, xmax, _, _ = Q.row_extents(m)
+        hull = np.asarray(Q.hull_of_extents(ys, xmin, xmax))
+        pts = np.argwhere(m)[:, ::-1]
+        ref = pts[ConvexHull(pts).vertices]
+        assert set(map(tuple, hull.tolist())) == set(map(tuple, ref.tolist()))
+
+
+@pytest.mark.parametrize("ang", [10, 75, 160, 250, 330])
+def test_agrees_with_host_orient(ang):
+    """the host classes (mtgv/adapters.py) trace a contour and use scipy; same quad up to a pixel on one blob"""
+    from mtgv.adapters import InstanceSeg, _largest_contour
+
+    m, _ = _rot_rect_mask(160, 160, 80, 80, 50, 72, ang, notch=0.3)
+    q, ok = Q.mask_quad(m)
+    seg = InstanceSeg(points=_largest_contour(m), label=0, conf=1.0)
+    host = np.asarray(seg.xyxyxyxy, np.float64)
+    assert ok == 1 and np.abs(q - host).max() <= 1.5, f"{q} vs {host}"
