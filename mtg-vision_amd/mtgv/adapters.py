@@ -336,26 +336,35 @@ class VectorStoreQdrant:
 
     def query_nearby(self, vector: list[float], k: int, *, with_payload: bool = True, with_vectors: bool = False,
                      score_threshold: float = None) -> list[ScoredPoint]:
-        if len(self._bank) == 0 or k <= 0:
-            return []
-        out = []
+        return self.query_nearby_batch([vector], k, with_payload=with_payload, with_vectors=with_vectors, score_threshold=score_threshold)[0]
+
+    def query_nearby_batch(self, vectors, k: int, *, with_payload: bool = True, with_vectors: bool = False,
+                           score_threshold: float = None) -> list[list[ScoredPoint]]:
+        """`query_nearby` for several query vectors in one GPU pass (one list of hits per query)."""
+        vectors = np.asarray(vectors, np.float32).reshape(-1, self._VECTOR_SIZE)
+        if len(self._bank) == 0 or k <= 0 or len(vectors) == 0:
+            return [[] for _ in range(len(vectors))]
         kk = min(int(k), len(self._bank))
-        ids, scores = self._bank.match(np.asarray(vector, np.float32), kk)
-        ids, scores = ids[0].cpu().numpy(), scores[0].cpu().numpy()
-        for i, s in zip(ids, scores):
-            if i < 0:
-                continue
-            if score_threshold is not None and not (s >= score_threshold):
-                continue
-            pid = self._ids[int(i)]
-            out.append(
-                ScoredPoint(
-                    id=pid, version=0, score=float(s),
-                    payload=deepcopy(self._payload.get(pid)) if with_payload else None,
-                    vector=self._bank.rows(int(i), 1)[0].tolist() if with_vectors else None,
+        ids, scores = self._bank.match(vectors, kk)
+        ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+        res = []
+        for row_ids, row_scores in zip(ids, scores):
+            out = []
+            for i, s in zip(row_ids, row_scores):
+                if i < 0:
+                    continue
+                if score_threshold is not None and not (s >= score_threshold):
+                    continue
+                pid = self._ids[int(i)]
+                out.append(
+                    ScoredPoint(
+                        id=pid, version=0, score=float(s),
+                        payload=deepcopy(self._payload.get(pid)) if with_payload else None,
+                        vector=self._bank.rows(int(i), 1)[0].tolist() if with_vectors else None,
+                    )
                 )
-            )
-        return out
+            res.append(out)
+        return res
 
     def update_payload(self, id_: str, payload: dict[str, Any]) -> QdrantPoint:
         self._payload[str(id_)] = deepcopy(payload)

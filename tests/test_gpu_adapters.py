@@ -122,3 +122,32 @@ def test_pipeline_overlap_equals_sequential(mode, _precision_guard):
     for a, b in zip(seq, ovl):
         for k in ("ids", "scores", "z", "crops", "boxes", "n_det"):
             assert torch.equal(a[k], b[k]), k
+
+
+def test_tracker_ctx_end_to_end():
+    """server.py's loop on the GPU stages: one batched embed + one batched query per frame == per-track calls"""
+    from mtgv import spec
+    from mtgv.adapters import CardSegmenter, CoreMlEncoder, QdrantPoint, VectorStoreQdrant
+    from mtgv.detector import Detector
+    from mtgv.tracker import TrackerCtx
+
+    cfg = spec.DetectorConfig()
+    seg = CardSegmenter(detector=Detector(cfg, spec.random_detector_state(cfg, 3), max_batch=1))
+    enc_cfg = spec.encoder_config("cnvnxt2ae_nano", (192, 128), "conv+linear")
+    enc = CoreMlEncoder(state_dict=spec.random_encoder_state(enc_cfg, 1), max_batch=16)
+    rng = np.random.default_rng(5)
+    db = VectorStoreQdrant(capacity=256)
+    db.save_points(QdrantPoint(id=f"id-{i}", vector=v.tolist(), payload={"n": i}) for i, v in enumerate(rng.standard_normal((200, 768)).astype(np.float32)))
+    frame = np.random.default_rng(8).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    now = [10.0]
+    ctx = TrackerCtx(0.5, 0.1, segmenter=seg, encoder=enc.model, vecs=db, clock=lambda: now[0])
+    assert ctx.update(frame) == [] and ctx.update(frame) == []
+    objs = ctx.update(frame)
+    assert len(objs) > 0
+    for o in objs[:4]:
+        z = enc.predict(o.last_rgb_im)
+        assert np.abs(o.avg_z - z).max() < 1e-5
+        want = db.query_nearby(o.avg_z, k=3)
+        assert [p.id for p in o.ave_nearby_points] == [p.id for p in want]
+        d = o.to_dict()
+        assert len(d["matches"]) == 3 and d["matches"][0]["all_data"] == want[0].payload and len(d["points"]) == 4
