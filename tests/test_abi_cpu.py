@@ -84,3 +84,26 @@ def test_product_does_not_import_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_gemm_precision_selection_without_gpu(libpath):
+    """default f16x3; MTGV_GEMM_PREC picks the initial mode; a bad value or a bad code is an AssertionError-class status"""
+    code = (
+        "import sys; sys.path[:0] = [%r]\n"
+        "from mtgv import native\n"
+        "print(native.get_gemm_precision())\n"
+        "native.set_gemm_precision('f32'); print(native.get_gemm_precision())\n"
+        "print(native.lib().mtgv_set_gemm_precision(5))\n"
+    ) % os.path.join(ROOT, "mtg-vision_amd")
+
+    def run(env_val):
+        env = {k: v for k, v in os.environ.items() if k != "MTGV_GEMM_PREC"}
+        if env_val is not None:
+            env["MTGV_GEMM_PREC"] = env_val
+        return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+
+    r = run(None)
+    assert r.returncode == 0 and r.stdout.split() == ["f16x3", "f32", "1"], r.stdout + r.stderr
+    assert run("f32").stdout.split()[0] == "f32"
+    bad = run("fp8")
+    assert bad.returncode != 0 and "AssertionError" in bad.stderr and "MTGV_GEMM_PREC" in bad.stderr
