@@ -1,5 +1,5 @@
-"""Randomised shape coverage of the GEMM / conv / top-k / NMS kernels (seeded, ~100 cases): ragged edges, tiny and
-odd sizes, every epilogue combination.  References are PyTorch CPU fp64 / the oracles."""
+"""Randomised shape coverage of the GEMM / conv / top-k / NMS kernels (seeded, ~100 cases, each under both GEMM
+operand modes): ragged edges, tiny and odd sizes, every epilogue combination.  References are PyTorch CPU fp64 / the oracles."""
 import numpy as np
 import pytest
 import torch
@@ -8,6 +8,17 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 ACTS = {0: lambda x: x, 1: F.gelu, 2: F.mish, 3: F.silu, 4: torch.sigmoid}
+
+
+@pytest.fixture(autouse=True, params=["f16x3", "f32"])
+def _both_gemm_precisions(request):
+    """every case of this module runs with both GEMM operand modes"""
+    from mtgv import native
+
+    before = native.get_gemm_precision()
+    native.set_gemm_precision(request.param)
+    yield
+    native.set_gemm_precision(before)
 
 
 def _dev(a):
