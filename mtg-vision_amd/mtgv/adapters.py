@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import spec
-from .crop import warp_quads
+from .crop import mask_quads, warp_quads
 from .detector import Detector, binarize_masks, letterbox
 from .encoder import Encoder
 from .matcher import Matcher
@@ -233,7 +233,12 @@ class CardSegmenter:
     `weights_only=True`; or pass `detector=` / `state_dict=`.  `.pt` pickles of whole ultralytics
     models are not loadable without the package (and are never unpickled here)."""
 
-    def __init__(self, model_path: str | Path = None, *, state_dict=None, detector: Optional[Detector] = None, max_batch: int = 1):
+    def __init__(self, model_path: str | Path = None, *, state_dict=None, detector: Optional[Detector] = None, max_batch: int = 1,
+                 contours: bool = True):
+        """contours=True (reference behaviour): `InstanceSeg.points` is the traced outline of the mask and the quad is
+        fitted lazily on the host.  contours=False: the oriented quad comes from the GPU (`mask_quads`, quads.hip) and
+        doubles as `points`; nothing but four corners per card leaves the device - the fast path for tracking loops."""
+        self.contours = contours
         if detector is not None:
             self.yolo = detector
         else:
@@ -248,6 +253,21 @@ class CardSegmenter:
         img, ratio, (left, top) = letterbox(rgb_im, self.yolo.cfg.imgsz)
         det = self.yolo.detect(rgb_im)
         detections = []
+        if not self.contours and det.mask_logits is not None and det.conf.numel() > 0:
+            quads, ok = mask_quads(binarize_masks(det.mask_logits), det.boxes_xyxy)
+            quads = (quads.cpu().numpy().astype(np.float64) - np.asarray([left, top], np.float64)) / float(ratio)
+            quads[..., 0] = np.clip(quads[..., 0], 0, rgb_im.shape[1])
+            quads[..., 1] = np.clip(quads[..., 1], 0, rgb_im.shape[0])
+            for q, good, conf in zip(quads, ok.cpu().numpy(), det.conf.cpu().numpy()):
+                if not good:
+                    continue
+                seg = InstanceSeg(points=q.astype(np.float32), label=0, conf=np.asarray(conf).tolist())
+                top_mid, centre = (q[0] + q[1]) / 2, q.mean(0)
+                v = top_mid - centre
+                seg._xyxyxyxy, seg._points_closed = q.astype(int), q.astype(int)
+                seg._dir_vec = v / (np.linalg.norm(v) or 1.0)
+                detections.append(seg)
+            return detections
         if det.mask_logits is not None and det.conf.numel() > 0:
             masks = binarize_masks(det.mask_logits).cpu().numpy()
             for m, conf in zip(masks, det.conf.cpu().numpy()):

@@ -151,3 +151,31 @@ def test_tracker_ctx_end_to_end():
         assert [p.id for p in o.ave_nearby_points] == [p.id for p in want]
         d = o.to_dict()
         assert len(d["matches"]) == 3 and d["matches"][0]["all_data"] == want[0].payload and len(d["points"]) == 4
+
+
+def test_card_segmenter_gpu_quads_fast_path():
+    """contours=False: quads fitted on the GPU, same cards and (up to a pixel or two) the same corners as the host path"""
+    from mtgv import spec
+    from mtgv.adapters import CardSegmenter
+    from mtgv.detector import Detector
+
+    cfg = spec.DetectorConfig()
+    det = Detector(cfg, spec.random_detector_state(cfg, 3), max_batch=1)
+    frame = np.random.default_rng(8).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    slow = CardSegmenter(detector=det)(frame)
+    fast = CardSegmenter(detector=det, contours=False)(frame)
+    assert len(fast) > 0 and len(fast) <= len(slow) + 0
+    assert all(s.points.shape == (4, 2) and s.xyxyxyxy.shape == (4, 2) and s.xyxyxyxy.dtype.kind == "i" for s in fast)
+    assert fast[0].extract_dewarped(frame).shape == (192, 128, 3)
+    assert abs(float(np.linalg.norm(fast[0].dir_vec)) - 1.0) < 1e-6
+    # random-weight masks are speckle, so only compare where the host path saw one blob: same corner set within 2 px
+    by_conf = {round(s.conf, 6): s for s in slow}
+    close = 0
+    for s in fast:
+        h = by_conf.get(round(s.conf, 6))
+        if h is None:
+            continue
+        a = np.sort(np.asarray(s.xyxyxyxy, float), axis=0)
+        b = np.sort(np.asarray(h.xyxyxyxy, float), axis=0)
+        close += int(np.abs(a - b).max() <= 2.0)
+    print(f"{len(fast)} fast / {len(slow)} host segments, {close} with the same corners")
