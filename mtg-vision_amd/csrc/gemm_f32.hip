@@ -205,6 +205,12 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   g.tiles_m = pl.tiles_m;
   g.tiles_n = pl.tiles_n;
   g.nseg_max = a.hw > 0 ? std::min(pl.bm(), (pl.bm() - 1) / a.hw + 2) : 1;
+  {
+    const double lim = 4294967296.0 - 65536.0;
+    const double a_bytes = (double)a.M * a.c_total * 4.0 + (double)a.c_off * 4.0, w_bytes = (double)a.N * a.K * 4.0;
+    const double s_bytes = a.a_scale != nullptr && a.hw > 0 ? (double)(a.M / a.hw) * a.K * 4.0 : 0.0;
+    g.off32_ok = a_bytes < lim && w_bytes < lim && s_bytes < lim;
+  }
   g.remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
   const int grid = pl.tiles_m * pl.tiles_n;
 

@@ -12,6 +12,8 @@
 #include "gemm_f32.h"
 #include "act.h"
 
+#include <type_traits>
+
 namespace mtgv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,6 +27,7 @@ struct GemmDev {
   int tiles_m, tiles_n;
   int remap;     // output rows are not simply m
   int nseg_max;  // APRO: images a 128-row tile can touch (sizes the LDS multiplier tile)
+  int off32_ok;  // every operand of the launch spans less than 4 GiB: 32-bit byte offsets are enough
 };
 
 // x = hi + lo + O(2^-22 |x|), both halves fp16, both rounded to nearest (fp16 subnormals are kept by the matrix unit).
@@ -143,7 +146,43 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
     const int m_end_t = (bm0 + BM < M_eff) ? bm0 + BM : M_eff;
     nseg_t = (int)fdiv((uint32_t)(m_end_t - 1), g.d_hw) - img_first_t + 1;
   }
-  auto load_tile = [&](int kt) {
+  // FAST (chosen per block, below): a dense tile that lies completely inside the problem with K a multiple of BK needs
+  // no predicates and no zero fill, and every address is a block-uniform base (advanced by the scalar unit) plus a
+  // 32-bit per-thread byte offset: 65 instead of 130 VALU instructions per K step of a 128x96 f16x3 tile (9 MFMAs).
+  // Measured effect on the whole step: -1 % GEMM time - the loop is not bound by VALU issue alone.
+  unsigned a_off[AP], b_off[BP], s_off[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    a_off[i] = (unsigned)((a_row[i] + lk) * (long)sizeof(float));
+    s_off[i] = (unsigned)((a_srow[i] + lk) * (long)sizeof(float));
+  }
+#pragma unroll
+  for (int i = 0; i < BP; ++i) b_off[i] = (unsigned)((b_row[i] + lk) * (long)sizeof(float));
+  auto load_tile = [&](int kt, auto fast_c) {
+    if constexpr (decltype(fast_c)::value) {
+      const char* const Ak = reinterpret_cast<const char*>(Ap) + (size_t)kt * BK * sizeof(float);
+      const char* const Wk = reinterpret_cast<const char*>(Wp) + (size_t)kt * BK * sizeof(float);
+#pragma unroll
+      for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ak + a_off[i]);
+      if (APRO && PREC == 1) {
+        const char* const Sk = reinterpret_cast<const char*>(p.a_scale) + (size_t)kt * BK * sizeof(float);
+#pragma unroll
+        for (int i = 0; i < AP; ++i) rsa[i] = *reinterpret_cast<const f32x4*>(Sk + s_off[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wk + b_off[i]);  // rows past BN: row 0, never stored
+      if (APRO && PREC == 0) {
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+          const int e = tid + u * 256;
+          const int seg = e / KQ, kq = (e % KQ) * 4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (seg < nseg_t) v = *reinterpret_cast<const f32x4*>(p.a_scale + (long)(img_first_t + seg) * p.K + kt * BK + kq);
+          rsl[u] = v;
+        }
+      }
+      return;
+    }
     const int k = kt * BK + lk;
     const bool kok = k < p.K;
     int kh = 0, kw = 0, c = 0;
@@ -252,67 +291,78 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
     seg_lane[i] = sg;
   }
   const int nk = (p.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const float* Ab = As + cur * BM * LS;
-    const float* Bb = Bs + cur * BN * LS;
-    if constexpr (PREC == 1) {
-      if (wave_active) {
-        const _Float16* const Ahi = Ah + (cur * 2 + 0) * BM * LSH;
-        const _Float16* const Alo = Ah + (cur * 2 + 1) * BM * LSH;
-        const _Float16* const Bhi = Bh + (cur * 2 + 0) * BN * LSH;
-        const _Float16* const Blo = Bh + (cur * 2 + 1) * BN * LSH;
+  auto k_loop = [&](auto fast_c) {
+    load_tile(0, fast_c);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) load_tile(kt + 1, fast_c);
+      const int cur = kt & 1;
+      const float* Ab = As + cur * BM * LS;
+      const float* Bb = Bs + cur * BN * LS;
+      if constexpr (PREC == 1) {
+        if (wave_active) {
+          const _Float16* const Ahi = Ah + (cur * 2 + 0) * BM * LSH;
+          const _Float16* const Alo = Ah + (cur * 2 + 1) * BM * LSH;
+          const _Float16* const Bhi = Bh + (cur * 2 + 0) * BN * LSH;
+          const _Float16* const Blo = Bh + (cur * 2 + 1) * BN * LSH;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-          // lane half h holds k = ks*16 + 8h + j in element j of both operands' fragments
-          const int ko = ks * 16 + 8 * half;
-          f16x8 ah[TM], al[TM];
+          for (int ks = 0; ks < BK / 16; ++ks) {
+            // lane half h holds k = ks*16 + 8h + j in element j of both operands' fragments
+            const int ko = ks * 16 + 8 * half;
+            f16x8 ah[TM], al[TM];
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            ah[i] = *reinterpret_cast<const f16x8*>(&Ahi[(arow + i * 32) * LSH + ko]);
-            al[i] = *reinterpret_cast<const f16x8*>(&Alo[(arow + i * 32) * LSH + ko]);
-          }
+            for (int i = 0; i < TM; ++i) {
+              ah[i] = *reinterpret_cast<const f16x8*>(&Ahi[(arow + i * 32) * LSH + ko]);
+              al[i] = *reinterpret_cast<const f16x8*>(&Alo[(arow + i * 32) * LSH + ko]);
+            }
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(&Bhi[(j * 32 + col) * LSH + ko]);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(&Blo[(j * 32 + col) * LSH + ko]);
+            for (int j = 0; j < TN; ++j) {
+              const f16x8 bh = *reinterpret_cast<const f16x8*>(&Bhi[(j * 32 + col) * LSH + ko]);
+              const f16x8 bl = *reinterpret_cast<const f16x8*>(&Blo[(j * 32 + col) * LSH + ko]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {  // small cross terms first, the hi*hi product last
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+              for (int i = 0; i < TM; ++i) {  // small cross terms first, the hi*hi product last
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+              }
             }
           }
         }
+      } else if (wave_active) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        // lane half h holds k = kk*8 + 4h + j in element j; A and B use the same
+        // k assignment, so MFMA j multiplies matching k pairs {j, 4+j}.
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          a[i] = *reinterpret_cast<const f32x4*>(&Ab[(arow + i * 32) * LS + kk * 8 + kh4]);
+          if (APRO) a[i] = a[i] * *reinterpret_cast<const f32x4*>(&Ss[(cur * g.nseg_max + seg_lane[i]) * BK + kk * 8 + kh4]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bb[(j * 32 + col) * LS + kk * 8 + kh4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
       }
-    } else if (wave_active) {
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      // lane half h holds k = kk*8 + 4h + j in element j; A and B use the same
-      // k assignment, so MFMA j multiplies matching k pairs {j, 4+j}.
-      f32x4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        a[i] = *reinterpret_cast<const f32x4*>(&Ab[(arow + i * 32) * LS + kk * 8 + kh4]);
-        if (APRO) a[i] = a[i] * *reinterpret_cast<const f32x4*>(&Ss[(cur * g.nseg_max + seg_lane[i]) * BK + kk * 8 + kh4]);
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bb[(j * 32 + col) * LS + kk * 8 + kh4]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      if (kt + 1 < nk) store_tile(cur ^ 1);
+      __syncthreads();
     }
-    }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
-    __syncthreads();
+  };
+  if constexpr (!CONV) {
+    const bool fast_tile = bm0 + BM <= M_eff && bn0 + BN <= p.N && p.K % BK == 0 && g.off32_ok;
+    if (fast_tile)
+      k_loop(std::true_type{});
+    else
+      k_loop(std::false_type{});
+  } else {
+    k_loop(std::false_type{});
   }
 
   if constexpr (EPI == 1) {
