@@ -194,7 +194,10 @@ Detector::Detector(const mtgv_detector_cfg& cfg) : cfg_(cfg) {
 }
 
 Detector::~Detector() {
-  for (float* p : dev_allocs_) (void)hipFree(p);
+  for (float* p : dev_allocs_) {
+    gemm_split_unregister(p);
+    (void)hipFree(p);
+  }
   if (nms_ws_) (void)hipFree(nms_ws_);
 }
 
@@ -220,6 +223,9 @@ float* Detector::upload(const std::vector<float>& v) {
   HIP_OK(hipMalloc((void**)&d, std::max<size_t>(v.size(), 4) * sizeof(float)));
   HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
   dev_allocs_.push_back(d);
+  gemm_split_register(d, v.size());  // weights become pre-split B operands for the f16x3 GEMMs (small vectors are skipped)
+  gemm_split_refresh(d, 0, v.size() % 4 == 0 ? v.size() : 0, nullptr);
+  HIP_OK(hipStreamSynchronize(nullptr));
   return d;
 }
 
@@ -273,7 +279,10 @@ View Detector::take(int n, int h, int w, int c) {
 void Detector::finalize() {
   MTGV_CHECK(missing() == 0, ERR_RUNTIME, "detector has %d unset parameters", missing());
   if (finalized_) return;
-  for (float* p : dev_allocs_) (void)hipFree(p);
+  for (float* p : dev_allocs_) {
+    gemm_split_unregister(p);
+    (void)hipFree(p);
+  }
   dev_allocs_.clear();
   cw_.clear();
   // every Conv+BN key prefix

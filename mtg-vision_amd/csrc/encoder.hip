@@ -32,7 +32,10 @@ void DevBuf::release() {
 // ---------------------------------------------------------------------------
 ParamStore::~ParamStore() {
   for (auto& kv : slots_)
-    if (kv.second.dev) (void)hipFree(kv.second.dev);
+    if (kv.second.dev) {
+      gemm_split_unregister(kv.second.dev);
+      (void)hipFree(kv.second.dev);
+    }
 }
 
 float* ParamStore::add(const std::string& key, std::vector<int> shape, Repack r, int perm_p, int perm_c, bool keep_host) {
@@ -45,6 +48,7 @@ float* ParamStore::add(const std::string& key, std::vector<int> shape, Repack r,
   sl.numel = 1;
   for (int d : shape) sl.numel *= d;
   HIP_OK(hipMalloc((void**)&sl.dev, (size_t)sl.numel * sizeof(float)));
+  if (shape.size() >= 2 && r != R_DW49) gemm_split_register(sl.dev, (size_t)sl.numel);  // conv / linear weights: B operands
   MTGV_CHECK(slots_.find(key) == slots_.end(), ERR_INVALID, "duplicate parameter %s", key.c_str());
   slots_[key] = sl;
   return sl.dev;
@@ -85,6 +89,10 @@ void ParamStore::set(const std::string& key, const float* host, int64_t numel) {
     src = tmp.data();
   }
   HIP_OK(hipMemcpy(sl.dev, src, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
+  if (gemm_split_lookup(sl.dev) != nullptr) {
+    gemm_split_refresh(sl.dev, 0, (size_t)numel, nullptr);
+    HIP_OK(hipStreamSynchronize(nullptr));
+  }
   if (sl.keep_host) sl.host.assign(host, host + numel);
   sl.set = true;
 }

@@ -15,6 +15,9 @@ namespace mtgv {
 struct GemmArgs {
   const float* A = nullptr;     // NHWC activation base
   const float* W = nullptr;     // [N][K]
+  // f16x3 only, optional: W with every aligned group of 4 floats replaced by their 4 fp16 hi + 4 fp16 lo halves
+  // (same byte layout, so the same offsets address it).  gemm_launch fills it in for registered weights.
+  const float* W_split = nullptr;
   float* Out = nullptr;
   const float* bias = nullptr;  // [N] or null
   const float* res = nullptr;   // residual [M][ldr] or null
@@ -82,6 +85,15 @@ int gemm_precision();
 void gemm_set_precision(int prec);
 // out[n] = bias[n] + W[n][:] . shift  (GRN beta folded into the next Linear's bias; a_shift is not applied by the GEMM)
 void fold_shift_into_bias_launch(const float* W, const float* shift, const float* bias, float* out, int N, int K, hipStream_t s);
+
+// Pre-split copies of constant B operands (weights, the bank) for the f16x3 mode: the loader then moves 16 bytes of
+// ready fp16 halves instead of converting the same weights in every block that uses them.  An owner registers the
+// base pointer of a buffer it allocated, refreshes a range after writing it, and unregisters before freeing.
+// gemm_launch looks W up by exact base pointer; unregistered operands are split on the fly as before.
+void gemm_split_register(const float* W, size_t n_floats);
+void gemm_split_refresh(const float* W, size_t offset_floats, size_t n_floats, hipStream_t s);
+void gemm_split_unregister(const float* W);
+const float* gemm_split_lookup(const float* W);
 
 // launch profiler for the roofline measurement (off by default; adds two event records per launch)
 void gemm_profile_enable(bool on);

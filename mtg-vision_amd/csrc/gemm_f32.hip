@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace mtgv {
@@ -109,6 +111,69 @@ static void prof_end(hipStream_t s) {
   g_prof.used += 2;
 }
 
+// ---------------------------------------------------------------------------
+// pre-split weight registry (f16x3)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ in, float* __restrict__ out, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f16x4 hi, lo;
+  split_f16(reinterpret_cast<const f32x4*>(in)[i], hi, lo);
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = hi[j], o[4 + j] = lo[j];
+  reinterpret_cast<f16x8*>(out)[i] = o;
+}
+
+namespace {
+struct SplitEntry {
+  float* buf = nullptr;
+  size_t n = 0;
+};
+std::map<const float*, SplitEntry> g_split;
+std::mutex g_split_mu;
+}  // namespace
+
+void gemm_split_register(const float* W, size_t n_floats) {
+  if (W == nullptr || n_floats < 64 || n_floats % 4 != 0 || ((uintptr_t)W % 16) != 0) return;
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  SplitEntry& e = g_split[W];
+  if (e.buf != nullptr && e.n == n_floats) return;
+  if (e.buf != nullptr) (void)hipFree(e.buf);
+  e.n = n_floats;
+  HIP_OK(hipMalloc((void**)&e.buf, n_floats * sizeof(float)));
+}
+
+void gemm_split_refresh(const float* W, size_t offset_floats, size_t n_floats, hipStream_t s) {
+  float* out = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_split.find(W);
+    if (it == g_split.end()) return;
+    MTGV_CHECK(offset_floats % 4 == 0 && n_floats % 4 == 0 && offset_floats + n_floats <= it->second.n, ERR_INVALID,
+               "split refresh outside the registered buffer");
+    out = it->second.buf;
+  }
+  if (n_floats == 0) return;
+  const long n4 = (long)(n_floats / 4);
+  hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W + offset_floats, out + offset_floats, n4);
+  HIP_OK(hipGetLastError());
+}
+
+void gemm_split_unregister(const float* W) {
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  auto it = g_split.find(W);
+  if (it == g_split.end()) return;
+  if (it->second.buf != nullptr) (void)hipFree(it->second.buf);
+  g_split.erase(it);
+}
+
+const float* gemm_split_lookup(const float* W) {
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  auto it = g_split.find(W);
+  return it == g_split.end() ? nullptr : it->second.buf;
+}
+
 static int g_prec = -1;  // -1: not read from the environment yet
 
 int gemm_precision() {
@@ -196,6 +261,8 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
 
   GemmDev g;
   g.a = a;
+  if (gemm_precision() == GEMM_PREC_F16X3 && g.a.W_split == nullptr && a.strideW == 0) g.a.W_split = gemm_split_lookup(a.W);
+  if (gemm_precision() != GEMM_PREC_F16X3) g.a.W_split = nullptr;
   g.d_ohw = make_fastdiv((uint32_t)(a.OH * a.OW));
   g.d_ow = make_fastdiv((uint32_t)a.OW);
   g.d_cin = make_fastdiv((uint32_t)a.Cin);

@@ -70,6 +70,9 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
   const int z = blockIdx.y;
   const float* const Ap = p.A + (long)z * p.strideA;
   const float* const Wp = p.W + (long)z * p.strideW;
+  // PREC 1: B already split into fp16 hi/lo halves in memory (registered weights / bank): no conversion work for it
+  const bool b_presplit = PREC == 1 && p.W_split != nullptr;
+  const float* const Wld = b_presplit ? p.W_split : Wp;
   float* const Op = p.Out + (long)z * p.strideO;
   int M_eff = p.M;
   if (p.m_count != nullptr) {
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
   auto load_tile = [&](int kt, auto fast_c) {
     if constexpr (decltype(fast_c)::value) {
       const char* const Ak = reinterpret_cast<const char*>(Ap) + (size_t)kt * BK * sizeof(float);
-      const char* const Wk = reinterpret_cast<const char*>(Wp) + (size_t)kt * BK * sizeof(float);
+      const char* const Wk = reinterpret_cast<const char*>(Wld) + (size_t)kt * BK * sizeof(float);
 #pragma unroll
       for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ak + a_off[i]);
       if (APRO && PREC == 1) {
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(Wp + b_row[i] + k);
+      if (b_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(Wld + b_row[i] + k);
       rb[i] = v;
     }
     if (APRO && PREC == 0) {
@@ -242,7 +245,12 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
       for (int i = 0; i < BP; ++i)
         if (lrow + i * RPP < BN) {
           f16x4 hi, lo;
-          split_f16(rb[i], hi, lo);
+          if (b_presplit) {
+            const f16x8 hl = __builtin_bit_cast(f16x8, rb[i]);
+            hi = f16x4{hl[0], hl[1], hl[2], hl[3]}, lo = f16x4{hl[4], hl[5], hl[6], hl[7]};
+          } else {
+            split_f16(rb[i], hi, lo);
+          }
           const int o = (lrow + i * RPP) * LSH + lk;
           *reinterpret_cast<f16x4*>(&Bh[(buf * 2 + 0) * BN * LSH + o]) = hi;
           *reinterpret_cast<f16x4*>(&Bh[(buf * 2 + 1) * BN * LSH + o]) = lo;

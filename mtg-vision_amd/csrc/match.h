@@ -8,6 +8,7 @@ namespace mtgv {
 class Bank {
  public:
   Bank(int dim, int64_t capacity);
+  ~Bank();
   int dim() const { return dim_; }
   int64_t size() const { return size_; }
   int64_t capacity() const { return cap_; }

@@ -58,7 +58,10 @@ Bank::Bank(int dim, int64_t capacity) : dim_(dim), cap_(capacity) {
   MTGV_CHECK(dim > 0 && dim % 4 == 0, ERR_INVALID, "bank: dim=%d must be a positive multiple of 4", dim);
   MTGV_CHECK(capacity > 0 && capacity < (1ll << 31), ERR_INVALID, "bank: capacity=%lld", (long long)capacity);
   vecs_.alloc((size_t)capacity * dim);
+  gemm_split_register(vecs_.p, (size_t)capacity * dim);  // the bank is the B operand of the match GEMM
 }
+
+Bank::~Bank() { gemm_split_unregister(vecs_.p); }
 
 void Bank::append(const float* v, int64_t n, bool is_device, hipStream_t s) {
   MTGV_CHECK(n >= 0 && size_ + n <= cap_, ERR_INVALID, "bank: %lld + %lld rows exceed capacity %lld", (long long)size_,
@@ -67,6 +70,7 @@ void Bank::append(const float* v, int64_t n, bool is_device, hipStream_t s) {
   float* dst = vecs_.p + (size_t)size_ * dim_;
   HIP_OK(hipMemcpyAsync(dst, v, (size_t)n * dim_ * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   l2norm_rows_launch(dst, dst, n, dim_, s);
+  gemm_split_refresh(vecs_.p, (size_t)size_ * dim_, (size_t)n * dim_, s);
   if (!is_device) HIP_OK(hipStreamSynchronize(s));  // host buffer may be freed by the caller
   size_ += n;
 }
@@ -76,6 +80,7 @@ void Bank::set_row(int64_t row, const float* v_host, hipStream_t s) {
   float* dst = vecs_.p + (size_t)row * dim_;
   HIP_OK(hipMemcpyAsync(dst, v_host, (size_t)dim_ * sizeof(float), hipMemcpyHostToDevice, s));
   l2norm_rows_launch(dst, dst, 1, dim_, s);
+  gemm_split_refresh(vecs_.p, (size_t)row * dim_, (size_t)dim_, s);
   HIP_OK(hipStreamSynchronize(s));
 }
 
