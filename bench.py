@@ -163,7 +163,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": precision,
+        # tensors, accumulation and results are f32 in both modes; f16x3 forms each f32 product from three fp16 MFMAs
+        # (error vs fp64 at the f32 level: tests/test_gpu_precision.py) - see config.gemm_operands
+        "dtype": "f32" if precision == "f32" else "f32 (products as 3 x f16 MFMA on hi/lo-split operands, f32 accumulate)",
         "data": "synthetic",
         "config": {
             "workload": f"full pipeline per GPU: {F} frames 640x640x3 u8 -> YOLOv8n-seg(nc=3) detect+NMS+masks -> {K} cards/frame "
@@ -174,6 +176,7 @@ def main():
             "bank": [a.bank, 768],
             "bank_layout": ("row-sharded %d-way + RCCL all-gather of per-shard top-1" % world) if sharded else "replicated",
             "weights": "random-init (seeded), no trained weights offline",
+            "gemm_precision_mode": precision,
             "gemm_operands": "f32 operands, f32-input MFMA" if precision == "f32" else "f32 tensors in HBM; GEMM operands split on the fly "
             "into fp16 hi+lo, 3 fp16 MFMAs per product, f32 accumulate (error vs fp64 at the f32 level, tests/test_gpu_precision.py)",
             "streams": "2 (detect of step i+1 beside embed+match of step i)" if overlap else "1",
