@@ -234,9 +234,11 @@ MTGV_API int mtgv_make_cropped(const uint8_t* images_dev, const int64_t* offsets
 MTGV_API int mtgv_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
                             int32_t m, int32_t n, int32_t k, int32_t act, void* stream);
 /* linear with the block's fused extras: rows are grouped in images of hw rows; a_scale (m/hw, k) and a_shift (k)
- * or NULL are applied to A on load (GRN apply); grn_part or NULL receives the per-tile sum(out^2) partials
- * (mtgv_op_linear_ex_part_floats floats). */
+ * or NULL are applied to A on load (GRN apply); grn_part or NULL receives the per-row-unit sum(out^2) partials
+ * (a buffer of mtgv_op_linear_ex_part_floats floats is large enough for any layout). */
 MTGV_API int64_t mtgv_op_linear_ex_part_floats(int32_t m, int32_t n, int32_t k, int32_t act, int32_t hw);
+/* layout of the partials the calling thread's last mtgv_op_linear_ex wrote: [ceil(m / unit_rows)][segmax][n] */
+MTGV_API int mtgv_op_last_grn_layout(int32_t* unit_rows, int32_t* segmax);
 MTGV_API int mtgv_op_linear_ex(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
                                int32_t m, int32_t n, int32_t k, int32_t act, int32_t hw, const float* a_scale_dev,
                                const float* a_shift_dev, float* grn_part_dev, void* stream);

@@ -5,12 +5,35 @@
 #include "encoder.h"
 #include "match.h"
 #include "rowops.h"
+#include "gemm_sp.h"
 
 namespace mtgv {
 const char* last_error_cstr();
 }
 
 using namespace mtgv;
+
+namespace {
+// The single-op entry points take raw weight pointers.  To run them on the same kernels the handles use, a constant
+// operand is registered (SP8 copy + row scales) for the duration of the call; the call then synchronises the stream.
+struct ScopedWeights {
+  const float* w = nullptr;
+  hipStream_t s;
+  ScopedWeights(const float* W, int n, int k, hipStream_t stream) : s(stream) {
+    if (W == nullptr || k % 8 != 0 || gemm_precision() != GEMM_PREC_F16X3 || ((uintptr_t)W % 16) != 0) return;
+    if (sp8_lookup(W, k, nullptr, nullptr)) return;  // the caller already owns a registration
+    sp8_register(W, (size_t)n * k, k);
+    sp8_refresh(W, 0, (size_t)n * k, s);
+    w = W;
+  }
+  ~ScopedWeights() {
+    if (w == nullptr) return;
+    (void)hipStreamSynchronize(s);
+    sp8_unregister(w);
+  }
+};
+thread_local GrnLayout t_last_grn;
+}  // namespace
 
 struct mtgv_encoder {
   Encoder impl;
@@ -167,6 +190,7 @@ MTGV_API int mtgv_op_linear(const float* a_dev, const float* w_dev, const float*
                             int32_t m, int32_t n, int32_t k, int32_t act, void* stream) {
   return guarded([&] {
     MTGV_CHECK(a_dev && w_dev && out_dev, ERR_INVALID, "null argument");
+    ScopedWeights reg(w_dev, n, k, (hipStream_t)stream);
     GemmArgs g = linear_args(a_dev, k, w_dev, bias_dev, out_dev, n, m, n, k, act);
     g.res = res_dev;
     g.ldr = n;
@@ -175,13 +199,22 @@ MTGV_API int mtgv_op_linear(const float* a_dev, const float* w_dev, const float*
 }
 MTGV_API int64_t mtgv_op_linear_ex_part_floats(int32_t m, int32_t n, int32_t k, int32_t act, int32_t hw) {
   if (m <= 0 || n <= 0 || k <= 0 || hw <= 0) return 0;
-  return (int64_t)gemm_grn_part_floats(gemm_plan(m, n, k, act != 0), n, hw);
+  (void)act;
+  return (int64_t)gemm_grn_part_floats_max(m, n, hw);
+}
+MTGV_API int mtgv_op_last_grn_layout(int32_t* unit_rows, int32_t* segmax) {
+  return guarded([&] {
+    MTGV_CHECK(unit_rows && segmax, ERR_INVALID, "null output");
+    *unit_rows = t_last_grn.unit_rows;
+    *segmax = t_last_grn.segmax;
+  });
 }
 MTGV_API int mtgv_op_linear_ex(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
                                int32_t m, int32_t n, int32_t k, int32_t act, int32_t hw, const float* a_scale_dev,
                                const float* a_shift_dev, float* grn_part_dev, void* stream) {
   return guarded([&] {
     MTGV_CHECK(a_dev && w_dev && out_dev, ERR_INVALID, "null argument");
+    ScopedWeights reg(w_dev, n, k, (hipStream_t)stream);
     GemmArgs g = linear_args(a_dev, k, w_dev, bias_dev, out_dev, n, m, n, k, act);
     g.res = res_dev;
     g.ldr = n;
@@ -195,8 +228,9 @@ MTGV_API int mtgv_op_linear_ex(const float* a_dev, const float* w_dev, const flo
     }
     const GemmPlan pl = gemm_plan(m, n, k, act != 0, a_scale_dev != nullptr);
     if (grn_part_dev) {
+      t_last_grn = gemm_grn_layout(g, pl);
       g.grn_part = grn_part_dev;
-      g.segmax = gemm_grn_segmax(pl, hw);
+      g.segmax = t_last_grn.segmax;
     }
     gemm_launch(g, pl, (hipStream_t)stream);
   });
@@ -249,6 +283,7 @@ MTGV_API int mtgv_op_block(const float* x_dev, float* out_dev, int32_t n, int32_
     bw.dw_w49 = (float*)dw_w49, bw.dw_b = (float*)dw_b, bw.ln_w = (float*)ln_w, bw.ln_b = (float*)ln_b;
     bw.w1 = (float*)w1, bw.b1 = (float*)b1, bw.gamma = (float*)gamma, bw.beta = (float*)beta;
     bw.w2 = (float*)w2, bw.b2 = (float*)b2;
+    ScopedWeights reg1(w1, 4 * c, c, (hipStream_t)stream), reg2(w2, c, 4 * c, (hipStream_t)stream);
     const BlockWsSize z = block_ws_size(n, h, w, c);
     BlockWs ws;
     ws.t1 = ws_dev;

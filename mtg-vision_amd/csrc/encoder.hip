@@ -10,6 +10,7 @@
 #include "encoder.h"
 #include <stdlib.h>
 #include "rowops.h"
+#include "gemm_sp.h"
 
 #include <string.h>
 
@@ -48,7 +49,8 @@ float* ParamStore::add(const std::string& key, std::vector<int> shape, Repack r,
   sl.numel = 1;
   for (int d : shape) sl.numel *= d;
   HIP_OK(hipMalloc((void**)&sl.dev, (size_t)sl.numel * sizeof(float)));
-  if (shape.size() >= 2 && r != R_DW49) gemm_split_register(sl.dev, (size_t)sl.numel);  // conv / linear weights: B operands
+  if (shape.size() >= 2 && r != R_DW49)  // conv / linear weights: B operands, rows of numel / shape[0] floats
+    gemm_split_register(sl.dev, (size_t)sl.numel, (int)(sl.numel / shape[0]));
   MTGV_CHECK(slots_.find(key) == slots_.end(), ERR_INVALID, "duplicate parameter %s", key.c_str());
   slots_[key] = sl;
   return sl.dev;
@@ -126,8 +128,7 @@ BlockWsSize block_ws_size(int n, int h, int w, int c) {
   const size_t M = (size_t)n * h * w;
   z.t = M * c;
   z.hid = M * 4 * c;
-  const GemmPlan pl = gemm_plan((int)M, 4 * c, c, true);
-  z.part = gemm_grn_part_floats(pl, 4 * c, h * w);
+  z.part = gemm_grn_part_floats_max((int)M, 4 * c, h * w);
   z.scale = (size_t)n * 4 * c;
   z.bfold = (size_t)c;
   return z;
@@ -136,21 +137,25 @@ BlockWsSize block_ws_size(int n, int h, int w, int c) {
 void run_block(const float* x, float* out, int n, int h, int w, int c, int act, const BlockW& bw, const BlockWs& ws,
                hipStream_t s) {
   const int M = n * h * w, hw = h * w;
+  // the normalised tensor has one consumer, pwconv1: written in SP8 when that launch runs on the LDS-DMA kernel
+  const int fmt = gemm_sp_takes_sp8(bw.w1, M, 4 * c, c, c, 0) ? 1 : 0;
   if (dwconv7_ln_supported(w, c)) {
-    dwconv7_ln_launch(x, bw.dw_w49, bw.dw_b, bw.ln_w, bw.ln_b, ws.t2, n, h, w, c, 1e-6f, s);
+    dwconv7_ln_launch(x, bw.dw_w49, bw.dw_b, bw.ln_w, bw.ln_b, ws.t2, n, h, w, c, 1e-6f, s, fmt);
   } else {
     dwconv7_launch(x, bw.dw_w49, bw.dw_b, ws.t1, n, h, w, c, s);
-    ln_rows_launch(ws.t1, c, 0, ws.t2, c, 0, bw.ln_w, bw.ln_b, M, c, 1e-6f, s);
+    ln_rows_launch(ws.t1, c, 0, ws.t2, c, 0, bw.ln_w, bw.ln_b, M, c, 1e-6f, s, fmt);
   }
 
   GemmArgs g1 = linear_args(ws.t2, c, bw.w1, bw.b1, ws.hid, 4 * c, M, 4 * c, c, act);
+  g1.a_fmt = fmt;
   const GemmPlan p1 = gemm_plan(M, 4 * c, c, true);
-  g1.grn_part = ws.part;
   g1.hw = hw;
-  g1.segmax = gemm_grn_segmax(p1, hw);
+  const GrnLayout gl = gemm_grn_layout(g1, p1);
+  g1.grn_part = ws.part;
+  g1.segmax = gl.segmax;
   gemm_launch(g1, p1, s);
 
-  grn_finalize_launch(ws.part, p1, n, hw, 4 * c, bw.gamma, ws.scale, s);
+  grn_finalize_launch(ws.part, gl, n, hw, 4 * c, bw.gamma, ws.scale, s);
 
   GemmArgs g2 = linear_args(ws.hid, 4 * c, bw.w2, bw.b2, out, c, M, c, 4 * c, ACT_NONE);
   g2.res = x;

@@ -14,6 +14,7 @@ namespace mtgv {
 
 struct GemmArgs {
   const float* A = nullptr;     // NHWC activation base
+  int a_fmt = 0;                // 0: f32; 1: SP8 (sp8.h) - only launches gemm_sp_plan accepts (gemm_sp_takes_sp8)
   const float* W = nullptr;     // [N][K]
   // f16x3 only, optional: W with every aligned group of 4 floats replaced by their 4 fp16 hi + 4 fp16 lo halves
   // (same byte layout, so the same offsets address it).  gemm_launch fills it in for registered weights.
@@ -90,7 +91,9 @@ void fold_shift_into_bias_launch(const float* W, const float* shift, const float
 // ready fp16 halves instead of converting the same weights in every block that uses them.  An owner registers the
 // base pointer of a buffer it allocated, refreshes a range after writing it, and unregisters before freeing.
 // gemm_launch looks W up by exact base pointer; unregistered operands are split on the fly as before.
-void gemm_split_register(const float* W, size_t n_floats);
+// row_k > 0 (a multiple of 8): the buffer holds rows of row_k floats; an SP8 copy with per-row scales is kept as well
+// and launches with K == row_k go to the LDS-DMA kernel (gemm_sp.h).
+void gemm_split_register(const float* W, size_t n_floats, int row_k = 0);
 void gemm_split_refresh(const float* W, size_t offset_floats, size_t n_floats, hipStream_t s);
 void gemm_split_unregister(const float* W);
 const float* gemm_split_lookup(const float* W);
@@ -102,9 +105,21 @@ void gemm_profile_read(double* ms, double* flops, long* launches);
 void gemm_profile_dump(const char* path);
 double gemm_profile_bytes();  // compulsory operand + result bytes of the launches recorded since enable
 
+// Layout of the GRN partial sums a launch with these arguments writes (grn_part itself need not be set yet):
+// [ceil(M / unit_rows)][segmax][N] floats.  Depends on which kernel gemm_launch will pick for the arguments.
+struct GrnLayout {
+  int unit_rows = 0, segmax = 0;
+  size_t floats = 0;
+};
+GrnLayout gemm_grn_layout(const GemmArgs& a, const GemmPlan& p);
+// upper bound of GrnLayout::floats over every kernel / tile that could be chosen
+size_t gemm_grn_part_floats_max(int M, int N, int hw);
+
 // sum the partials of one GEMM into the GRN apply table
 //   scale[img][n] = gamma[n] * Gx / (mean_n Gx + 1e-6) + 1,  Gx = sqrt(sum x^2)
 void grn_finalize_launch(const float* part, const GemmPlan& p, int n_img, int hw, int N, const float* gamma,
                          float* scale, hipStream_t s);
+void grn_finalize_launch(const float* part, const GrnLayout& l, int n_img, int hw, int N, const float* gamma, float* scale,
+                         hipStream_t s);
 
 }  // namespace mtgv

@@ -7,6 +7,7 @@
 //   f16x3  each f32 operand split into fp16 hi + lo, three fp16 MFMAs per product (gemm_f16x3.hip);
 //          measured error vs fp64 is at the f32 level (tools/micro/split_gemm.hip, tests/test_gpu_precision.py)
 #include "gemm_kernel.h"
+#include "gemm_sp.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -134,8 +135,9 @@ std::map<const float*, SplitEntry> g_split;
 std::mutex g_split_mu;
 }  // namespace
 
-void gemm_split_register(const float* W, size_t n_floats) {
+void gemm_split_register(const float* W, size_t n_floats, int row_k) {
   if (W == nullptr || n_floats < 64 || n_floats % 4 != 0 || ((uintptr_t)W % 16) != 0) return;
+  if (row_k > 0) sp8_register(W, n_floats, row_k);
   std::lock_guard<std::mutex> lk(g_split_mu);
   SplitEntry& e = g_split[W];
   if (e.buf != nullptr && e.n == n_floats) return;
@@ -145,6 +147,7 @@ void gemm_split_register(const float* W, size_t n_floats) {
 }
 
 void gemm_split_refresh(const float* W, size_t offset_floats, size_t n_floats, hipStream_t s) {
+  sp8_refresh(W, offset_floats, n_floats, s);
   float* out = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_split_mu);
@@ -161,6 +164,7 @@ void gemm_split_refresh(const float* W, size_t offset_floats, size_t n_floats, h
 }
 
 void gemm_split_unregister(const float* W) {
+  sp8_unregister(W);
   std::lock_guard<std::mutex> lk(g_split_mu);
   auto it = g_split.find(W);
   if (it == g_split.end()) return;
@@ -242,6 +246,30 @@ size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw) {
   return (size_t)p.tiles_m * gemm_grn_segmax(p, hw) * N;
 }
 
+GrnLayout gemm_grn_layout(const GemmArgs& a, const GemmPlan& p) {
+  GrnLayout l;
+  const SpPlan sp = gemm_sp_plan(a);
+  const int hw = a.hw > 0 ? a.hw : 1;
+  if (sp.cfg >= 0) {
+    l.unit_rows = sp.unit_rows;
+    l.segmax = (sp.unit_rows - 1) / hw + 2;
+  } else {
+    l.unit_rows = p.bm();
+    l.segmax = gemm_grn_segmax(p, hw);
+  }
+  l.floats = (size_t)ceil_div(a.M, l.unit_rows) * l.segmax * a.N;
+  return l;
+}
+
+size_t gemm_grn_part_floats_max(int M, int N, int hw) {
+  size_t mx = 0;
+  for (int unit : {32, 64, 128, 256}) {
+    const size_t f = (size_t)ceil_div(M, unit) * ((unit - 1) / hw + 2) * N;
+    mx = f > mx ? f : mx;
+  }
+  return mx;
+}
+
 void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   MTGV_CHECK(a.batch >= 1 && a.batch <= 65535, ERR_INVALID, "gemm: batch=%d", a.batch);
   MTGV_CHECK(a.M > 0 && a.N > 0 && a.K > 0, ERR_INVALID, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -257,6 +285,16 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   MTGV_CHECK(a.a_shift == nullptr, ERR_INVALID, "gemm: fold the GRN shift into the bias (fold_shift_into_bias_launch)");
   if (!conv) MTGV_CHECK(a.OH == a.H && a.OW == a.Wd, ERR_INVALID, "gemm: 1x1 geometry mismatch");
   if (apro || a.grn_part) MTGV_CHECK(a.hw > 0 && a.M % a.hw == 0, ERR_INVALID, "gemm: hw=%d must divide M=%d", a.hw, a.M);
+  {
+    const SpPlan sp = gemm_sp_plan(a);  // the LDS-DMA split kernel takes every launch it can run
+    if (sp.cfg >= 0) {
+      if (a.grn_part) MTGV_CHECK(a.hw > 0 && a.M % a.hw == 0, ERR_INVALID, "gemm: hw=%d must divide M=%d", a.hw, a.M);
+      prof_begin(a, s);
+      gemm_sp_launch(a, sp, s);
+      prof_end(s);
+      return;
+    }
+  }
   if (a.grn_part) MTGV_CHECK(a.segmax >= gemm_grn_segmax(pl, a.hw), ERR_INVALID, "gemm: segmax too small");
 
   GemmDev g;
@@ -347,13 +385,21 @@ void fold_shift_into_bias_launch(const float* W, const float* shift, const float
   HIP_OK(hipGetLastError());
 }
 
-void grn_finalize_launch(const float* part, const GemmPlan& p, int n_img, int hw, int N, const float* gamma, float* scale,
+void grn_finalize_launch(const float* part, const GrnLayout& l, int n_img, int hw, int N, const float* gamma, float* scale,
                          hipStream_t s) {
   const size_t lds = (size_t)(N + 256) * sizeof(float);
   MTGV_CHECK(lds <= 160 * 1024, ERR_INVALID, "grn_finalize: N=%d too large", N);
-  hipLaunchKernelGGL(grn_finalize_kernel, dim3(n_img), dim3(256), lds, s, part, p.bm(), gemm_grn_segmax(p, hw), hw, N,
-                     make_fastdiv((uint32_t)hw), make_fastdiv((uint32_t)p.bm()), gamma, scale);
+  hipLaunchKernelGGL(grn_finalize_kernel, dim3(n_img), dim3(256), lds, s, part, l.unit_rows, l.segmax, hw, N,
+                     make_fastdiv((uint32_t)hw), make_fastdiv((uint32_t)l.unit_rows), gamma, scale);
   HIP_OK(hipGetLastError());
+}
+
+void grn_finalize_launch(const float* part, const GemmPlan& p, int n_img, int hw, int N, const float* gamma, float* scale,
+                         hipStream_t s) {
+  GrnLayout l;
+  l.unit_rows = p.bm();
+  l.segmax = gemm_grn_segmax(p, hw);
+  grn_finalize_launch(part, l, n_img, hw, N, gamma, scale, s);
 }
 
 }  // namespace mtgv

@@ -1,0 +1,34 @@
+// Host side of the LDS-DMA split-precision GEMM (gemm_sp_kernel.h): SP8 copies of constant B operands, tile
+// selection, launch.  gemm_launch (gemm_f32.hip) routes every eligible f16x3 launch here.
+#pragma once
+#include "gemm_f32.h"
+
+namespace mtgv {
+
+// SP8 copy (+ per-row power-of-two scale) of a constant [rows][row_k] f32 operand, keyed by its base pointer.
+// Owners call these through gemm_split_register / _refresh / _unregister (gemm_f32.h).
+void sp8_register(const float* W, size_t n_floats, int row_k);
+void sp8_refresh(const float* W, size_t offset_floats, size_t n_floats, hipStream_t s);
+void sp8_unregister(const float* W);
+// SP8 rows and scales for the operand at `W` (base or a row-aligned interior pointer of a registered buffer) when its
+// rows are K long; false if there is none
+bool sp8_lookup(const float* W, int K, const char** sp8, const float** wscale);
+
+struct SpPlan {
+  int cfg = -1;          // index into the instantiated tile configurations; -1: not eligible
+  int bm = 0, bn = 0;
+  int unit_rows = 0;     // rows of one GRN partial unit (a wave's rows)
+  int tiles_m = 0, tiles_n = 0;
+};
+
+// Can (and should) this launch run on the SP kernel?  a.a_fmt says how A is stored.
+SpPlan gemm_sp_plan(const GemmArgs& a);
+// true when a dense [M][K] x [N][K]^T launch with these sizes would take SP8 activations (producer kernels ask before
+// choosing their output format)
+bool gemm_sp_takes_sp8(const float* W, int M, int N, int K, int lda, int c_off);
+void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s);
+
+// f32 [rows][K] -> SP8 rows, unscaled (activations; test surface)
+void sp8_pack_plain_launch(const float* in, void* out, long rows, int K, hipStream_t s);
+
+}  // namespace mtgv

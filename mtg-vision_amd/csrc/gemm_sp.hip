@@ -1,0 +1,286 @@
+// LDS-DMA split-precision GEMM: instantiations, SP8 operand registry, tile selection, launch.
+#include "gemm_sp.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <mutex>
+
+#include "gemm_sp_kernel.h"
+
+namespace mtgv {
+
+// ---------------------------------------------------------------------------
+// SP8 packing
+// ---------------------------------------------------------------------------
+// One wave per row: row maximum -> power-of-two scale (maximum lands in [2^13, 2^14)) -> split.  wscale = 2^-e.
+__global__ __launch_bounds__(256) void sp8_pack_rows_kernel(const float* __restrict__ in, sp_h8* __restrict__ out,
+                                                           float* __restrict__ wscale, long rows, int K) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = in + row * K;
+  float mx = 0.f;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(x[k]));
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+  int e = 0;
+  if (mx > 0.f && mx < INFINITY) {
+    int ex;
+    (void)frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)
+    e = 14 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+  const float sc = ldexpf(1.0f, e);
+  if (lane == 0) wscale[row] = ldexpf(1.0f, -e);
+  sp_h8* o = out + row * (K / 4);  // two 16-byte pieces per chunk of 8
+  for (int c = lane; c < K / 8; c += 64) {
+    const sp_f4 a = *reinterpret_cast<const sp_f4*>(x + c * 8) * sc, b = *reinterpret_cast<const sp_f4*>(x + c * 8 + 4) * sc;
+    sp_h8 hi, lo;
+    sp8_split8(a, b, hi, lo);
+    o[2 * c] = hi;
+    o[2 * c + 1] = lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void sp8_pack_plain_kernel(const float* __restrict__ in, sp_h8* __restrict__ out, long n8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  sp_h8 hi, lo;
+  sp8_split8(*reinterpret_cast<const sp_f4*>(in + i * 8), *reinterpret_cast<const sp_f4*>(in + i * 8 + 4), hi, lo);
+  out[2 * i] = hi;
+  out[2 * i + 1] = lo;
+}
+
+void sp8_pack_plain_launch(const float* in, void* out, long rows, int K, hipStream_t s) {
+  MTGV_CHECK(K % 8 == 0, ERR_INVALID, "sp8: K=%d must be a multiple of 8", K);
+  const long n8 = rows * (K / 8);
+  if (n8 <= 0) return;
+  hipLaunchKernelGGL(sp8_pack_plain_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, in, (sp_h8*)out, n8);
+  HIP_OK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// registry
+// ---------------------------------------------------------------------------
+namespace {
+struct Sp8Entry {
+  char* buf = nullptr;     // SP8 rows
+  float* wscale = nullptr; // [rows]
+  size_t n = 0;            // floats of the master
+  int row_k = 0;
+};
+std::map<const float*, Sp8Entry> g_sp8;
+std::mutex g_sp8_mu;
+char* g_zero = nullptr;
+
+const char* zero_page() {
+  std::lock_guard<std::mutex> lk(g_sp8_mu);
+  if (g_zero == nullptr) {
+    HIP_OK(hipMalloc((void**)&g_zero, 256));
+    HIP_OK(hipMemset(g_zero, 0, 256));
+  }
+  return g_zero;
+}
+}  // namespace
+
+void sp8_register(const float* W, size_t n_floats, int row_k) {
+  if (W == nullptr || row_k <= 0 || row_k % 8 != 0 || n_floats == 0 || n_floats % (size_t)row_k != 0 || ((uintptr_t)W % 16) != 0) return;
+  std::lock_guard<std::mutex> lk(g_sp8_mu);
+  Sp8Entry& e = g_sp8[W];
+  if (e.buf != nullptr && e.n == n_floats && e.row_k == row_k) return;
+  if (e.buf != nullptr) (void)hipFree(e.buf);
+  if (e.wscale != nullptr) (void)hipFree(e.wscale);
+  e.n = n_floats;
+  e.row_k = row_k;
+  HIP_OK(hipMalloc((void**)&e.buf, n_floats * sizeof(float)));
+  HIP_OK(hipMalloc((void**)&e.wscale, (n_floats / row_k) * sizeof(float)));
+}
+
+void sp8_refresh(const float* W, size_t offset_floats, size_t n_floats, hipStream_t s) {
+  Sp8Entry e;
+  {
+    std::lock_guard<std::mutex> lk(g_sp8_mu);
+    auto it = g_sp8.find(W);
+    if (it == g_sp8.end()) return;
+    e = it->second;
+  }
+  if (n_floats == 0) return;
+  MTGV_CHECK(offset_floats % e.row_k == 0 && n_floats % e.row_k == 0 && offset_floats + n_floats <= e.n, ERR_INVALID,
+             "sp8 refresh must cover whole rows inside the registered buffer");
+  const long row0 = (long)(offset_floats / e.row_k), rows = (long)(n_floats / e.row_k);
+  hipLaunchKernelGGL(sp8_pack_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, W + offset_floats,
+                     reinterpret_cast<sp_h8*>(e.buf + offset_floats * sizeof(float)), e.wscale + row0, rows, e.row_k);
+  HIP_OK(hipGetLastError());
+}
+
+void sp8_unregister(const float* W) {
+  std::lock_guard<std::mutex> lk(g_sp8_mu);
+  auto it = g_sp8.find(W);
+  if (it == g_sp8.end()) return;
+  if (it->second.buf != nullptr) (void)hipFree(it->second.buf);
+  if (it->second.wscale != nullptr) (void)hipFree(it->second.wscale);
+  g_sp8.erase(it);
+}
+
+bool sp8_lookup(const float* W, int K, const char** sp8, const float** wscale) {
+  std::lock_guard<std::mutex> lk(g_sp8_mu);
+  if (g_sp8.empty()) return false;
+  auto it = g_sp8.upper_bound(W);  // first base > W
+  if (it == g_sp8.begin()) return false;
+  --it;
+  const Sp8Entry& e = it->second;
+  const size_t off = (size_t)(W - it->first);
+  if (off >= e.n || e.row_k != K || off % (size_t)K != 0) return false;
+  if (sp8) *sp8 = e.buf + off * sizeof(float);
+  if (wscale) *wscale = e.wscale + off / K;
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// tile configurations
+// ---------------------------------------------------------------------------
+namespace {
+struct SpCfg {
+  int wm, wn, tm, tn;
+  double eff;  // relative MFMA efficiency of the tile (fitted to tools/gemm_sp_sweep.py)
+  int bm() const { return 32 * tm * wm; }
+  int bn() const { return 32 * tn * wn; }
+};
+constexpr int KS_ = 2;
+const SpCfg kCfg[] = {
+    {2, 2, 2, 2, 0.93},  // 128 x 128
+    {2, 2, 2, 3, 1.00},  // 128 x 192
+    {4, 1, 1, 3, 0.88},  // 128 x  96
+};
+constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
+
+bool sp_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MTGV_GEMM_SP");
+    on = (e != nullptr && !strcmp(e, "0")) ? 0 : 1;
+  }
+  return on != 0;
+}
+}  // namespace
+
+bool gemm_sp_takes_sp8(const float* W, int M, int N, int K, int lda, int c_off) {
+  if (!sp_enabled() || gemm_precision() != GEMM_PREC_F16X3) return false;
+  if (K % 8 != 0 || N % 4 != 0 || lda % 8 != 0 || c_off % 8 != 0 || M <= 0) return false;
+  return sp8_lookup(W, K, nullptr, nullptr);
+}
+
+SpPlan gemm_sp_plan(const GemmArgs& a) {
+  SpPlan pl;
+  const bool sp8_in = a.a_fmt == 1;
+  auto none = [&]() -> SpPlan {
+    MTGV_CHECK(!sp8_in, ERR_INVALID, "gemm: SP8 activations handed to a launch the SP kernel cannot run");
+    return pl;
+  };
+  if (!sp_enabled() || gemm_precision() != GEMM_PREC_F16X3) return none();
+  const bool conv = !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.stride_w <= 1 && a.pad == 0);
+  const bool remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
+  if (conv || remap || a.batch != 1 || a.topk > 0 || a.crop_boxes != nullptr || a.m_count != nullptr) return none();
+  if (a.K % 8 != 0 || a.N % 4 != 0 || a.c_total % 8 != 0 || a.c_off % 8 != 0 || a.ldo % 4 != 0 || a.o_off % 4 != 0 ||
+      (a.res != nullptr && a.ldr % 4 != 0))
+    return none();
+  if (((uintptr_t)a.Out % 16) != 0 || (a.res != nullptr && ((uintptr_t)a.res % 16) != 0)) return none();
+  if (sp8_in && a.a_scale != nullptr) return none();
+  if (!sp8_lookup(a.W, a.K, nullptr, nullptr)) return none();
+  if (!sp8_in && (a.N < 64 || a.M < 128)) return none();  // tiny problems: the convert-on-load kernel's narrow tiles fit better
+
+  int best = -1;
+  double best_cost = 0;
+  if (const char* e = getenv("MTGV_SP_CFG")) {
+    const int c = atoi(e);
+    if (c >= 0 && c < kNumCfg) best = c;
+  }
+  if (best < 0) {
+    for (int c = 0; c < kNumCfg; ++c) {
+      const SpCfg& k = kCfg[c];
+      const long tiles = (long)ceil_div(a.M, k.bm()) * ceil_div(a.N, k.bn());
+      // two blocks per CU: a "round" is up to 512 tiles, each CU working on two at half speed
+      const double rounds = (double)((tiles + 511) / 512);
+      const double per_cu = rounds * 2.0 * k.bm() * k.bn();
+      const double cost = per_cu / k.eff;
+      if (best < 0 || cost < best_cost) best = c, best_cost = cost;
+    }
+  }
+  const SpCfg& k = kCfg[best];
+  pl.cfg = best;
+  pl.bm = k.bm(), pl.bn = k.bn();
+  pl.unit_rows = 32 * k.tm;
+  pl.tiles_m = ceil_div(a.M, k.bm());
+  pl.tiles_n = ceil_div(a.N, k.bn());
+  return pl;
+}
+
+template <int WM, int WN, int TM, int TN, int AMODE, int ACT>
+static void sp_launch_one(const SpDev& g, hipStream_t s) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * 64 * KS_;
+  static bool attr_done = false;
+  auto kern = gemm_sp_kernel<WM, WN, TM, TN, KS_, AMODE, ACT>;
+  if (!attr_done) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * WM * WN), lds, s, g);
+}
+
+template <int WM, int WN, int TM, int TN>
+static void sp_launch_cfg(const SpDev& g, bool sp8_in, hipStream_t s) {
+  if (sp8_in) {
+    switch (g.act) {
+      case ACT_NONE: sp_launch_one<WM, WN, TM, TN, 0, ACT_NONE>(g, s); break;
+      case ACT_MISH: sp_launch_one<WM, WN, TM, TN, 0, ACT_MISH>(g, s); break;
+      case ACT_GELU: sp_launch_one<WM, WN, TM, TN, 0, ACT_GELU>(g, s); break;
+      case ACT_SILU: sp_launch_one<WM, WN, TM, TN, 0, ACT_SILU>(g, s); break;
+      default: sp_launch_one<WM, WN, TM, TN, 0, -1>(g, s); break;
+    }
+  } else {
+    if (g.act == ACT_NONE) sp_launch_one<WM, WN, TM, TN, 1, ACT_NONE>(g, s);
+    else sp_launch_one<WM, WN, TM, TN, 1, -1>(g, s);
+  }
+}
+
+void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
+  MTGV_CHECK(pl.cfg >= 0 && pl.cfg < kNumCfg, ERR_INVALID, "gemm_sp: no plan");
+  SpDev g;
+  g.A = reinterpret_cast<const char*>(a.A);
+  g.a_rowb = (long)a.c_total * 4;
+  g.a_offb = (long)a.c_off * 4;
+  const char* w8 = nullptr;
+  const float* wsc = nullptr;
+  MTGV_CHECK(sp8_lookup(a.W, a.K, &w8, &wsc), ERR_RUNTIME, "gemm_sp: weights lost their SP8 copy");
+  g.W = w8;
+  g.wscale = wsc;
+  g.bias = a.bias;
+  g.res = a.res;
+  g.ldr = a.ldr;
+  g.Out = a.Out;
+  g.ldo = a.ldo;
+  g.o_off = a.o_off;
+  g.M = a.M, g.N = a.N, g.K = a.K;
+  g.grn_part = a.grn_part;
+  g.hw = a.hw > 0 ? a.hw : 1;
+  g.segmax = a.segmax;
+  g.d_hw = make_fastdiv((uint32_t)g.hw);
+  g.a_scale = a.a_scale;
+  g.zero = zero_page();
+  g.tiles_m = pl.tiles_m, g.tiles_n = pl.tiles_n;
+  g.act = a.act;
+  if (a.grn_part != nullptr)
+    MTGV_CHECK(a.segmax >= (pl.unit_rows - 1) / g.hw + 2, ERR_INVALID, "gemm_sp: segmax %d too small", a.segmax);
+  const bool sp8_in = a.a_fmt == 1;
+  switch (pl.cfg) {
+    case 0: sp_launch_cfg<2, 2, 2, 2>(g, sp8_in, s); break;
+    case 1: sp_launch_cfg<2, 2, 2, 3>(g, sp8_in, s); break;
+    case 2: sp_launch_cfg<4, 1, 1, 3>(g, sp8_in, s); break;
+    default: MTGV_CHECK(false, ERR_INVALID, "gemm_sp: bad cfg %d", pl.cfg);
+  }
+  HIP_OK(hipGetLastError());
+}
+
+}  // namespace mtgv

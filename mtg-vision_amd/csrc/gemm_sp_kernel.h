@@ -1,0 +1,350 @@
+// Split-precision GEMM, second generation: operands arrive in LDS already split (SP8, sp8.h) and the K loop is
+// pure LDS-DMA + ds_read_b128 + MFMA.
+//
+//   Out[m][o_off + n] = act( sum_k A[m][k] * W[n][k] * wscale[n] + bias[n] ) (+ res[m][n])
+//
+// Block: WM x WN waves; wave tile (32*TM) rows x (32*TN) columns; K in stages of 16*KS (RB = 64*KS bytes per staged
+// row), two LDS buffers, one raw s_barrier per stage.
+//   B (weights)          always by LDS-DMA (global_load_lds_dwordx4) from the registered SP8 copy.
+//   A, AMODE 0 (DMA)     SP8 activation rows written by the producer kernel (LayerNorm / dwconv+LN): LDS-DMA.
+//   A, AMODE 1 (REG)     f32 rows: global -> VGPR (issued before the stage's MFMAs) -> optional per-image multiplier
+//                        (GRN apply, convnextv2.py:171-174) -> split -> ds_write_b128 (after the MFMAs).
+// LDS image of a stage: [row][SPR slots of 16 B], slot' = slot ^ sw(row), sw = (row>>1)&7 for 128-byte rows,
+// (row>>2)&3 for 64-byte rows: every ds_read_b128 lane group covers all 64 banks once.  The DMA destination is
+// lane-linear, so the swizzle is applied to the per-lane source address (and to the ds_write address in REG mode).
+//
+// MFMA orientation: weights are the first operand, so the accumulator has n on registers and m on lanes - a lane owns
+// one output row and 4 consecutive columns per register group.  The epilogue (wscale, bias, activation in registers;
+// GRN sum(x^2) partials by cross-lane adds) stages each 32-row slab through LDS so that global stores and residual
+// loads are whole 128-byte lines.
+//
+// Products: lo*hi + hi*lo + hi*hi per k16 step into the same accumulator, k ascending: results do not depend on the
+// tile configuration.
+#pragma once
+#include "act.h"
+#include "gemm_f32.h"
+#include "sp8.h"
+
+namespace mtgv {
+
+typedef float spf16 __attribute__((ext_vector_type(16)));
+
+struct SpDev {
+  const char* A = nullptr;      // AMODE 0: SP8 bytes; AMODE 1: f32
+  long a_rowb = 0;              // bytes per A row
+  long a_offb = 0;              // byte offset of the first channel used
+  const char* W = nullptr;      // SP8 [N][K]
+  const float* wscale = nullptr;  // [N]
+  const float* bias = nullptr;
+  const float* res = nullptr;
+  long ldr = 0;
+  float* Out = nullptr;
+  long ldo = 0;
+  int o_off = 0;
+  int M = 0, N = 0, K = 0;
+  float* grn_part = nullptr;    // [units][segmax][N], unit = one wave's rows (32*TM)
+  int hw = 1, segmax = 0;
+  FastDiv d_hw;
+  const float* a_scale = nullptr;  // AMODE 1: [M/hw][K]
+  const char* zero = nullptr;   // >= 16 zero bytes (K tail of the DMA path)
+  int tiles_m = 0, tiles_n = 0;
+  int act = 0;
+};
+
+typedef const __attribute__((address_space(1))) void* sp_gptr;
+typedef __attribute__((address_space(3))) void* sp_lptr;
+
+// sum over the 32 lanes that share lane>>5 (fixed order), result in every lane of the half
+__device__ __forceinline__ float sp_sum32(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm 1,0,3,2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm 2,3,0,1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                // lane ^ 16
+  return v;
+}
+
+template <int WM, int WN, int TM, int TN, int KS, int AMODE, int ACT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g) {
+#pragma clang fp contract(off)
+  constexpr int NW = WM * WN, NT = 64 * NW, BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int RB = 64 * KS, RPP = 1024 / RB, SPR = RB / 16;
+  constexpr int SA = BM * RB, SB = BN * RB, STG = SA + SB;
+  constexpr int PA = AMODE == 0 ? BM / RPP : 0, PB = BN / RPP, NP = PA + PB;
+  constexpr int PPW = (NP + NW - 1) / NW;
+  constexpr int CPS = BM * 2 * KS;                  // REG: 8-float chunks of A per stage
+  constexpr int CPT = AMODE == 1 ? CPS / NT : 1;    // per thread
+  static_assert(AMODE == 0 || CPS % NT == 0, "A chunks must divide over the threads");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  int L;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7, x = b & 7;
+    L = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (b >> 3);
+  }
+  const int tile_n = L % g.tiles_n, tile_m = L / g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const long wrowb = (long)g.K * 4;
+  const int kchunks = g.K >> 3;                 // valid 8-float chunks per row
+  const int nk = (g.K + 16 * KS - 1) / (16 * KS);
+  const bool ktail = (g.K % (16 * KS)) != 0;
+
+  // ---- DMA pieces: piece p = wave + NW*u of the stage image (A pieces first, then B) ----
+  const char* src[PPW];
+  bool tailz[PPW];
+#pragma unroll
+  for (int u = 0; u < PPW; ++u) {
+    const int p = wave + NW * u;
+    const bool isA = p < PA;
+    const int pp = isA ? p : p - PA;
+    const int row = pp * RPP + lane / SPR;
+    const int sw = KS == 2 ? (row >> 1) & 7 : (row >> 2) & 3;
+    const int slot = (lane % SPR) ^ sw;
+    if (isA) {
+      int m = m0 + row;
+      m = m < g.M ? m : g.M - 1;
+      src[u] = g.A + (long)m * g.a_rowb + g.a_offb + slot * 16;
+    } else {
+      int n = n0 + row;
+      n = n < g.N ? n : g.N - 1;
+      src[u] = g.W + (long)n * wrowb + slot * 16;
+    }
+    tailz[u] = ktail && ((nk - 1) * 2 * KS + (slot >> 1)) >= kchunks;
+  }
+  auto issue = [&](int t, int buf) {
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+      const int p = wave + NW * u;
+      if (NP % NW == 0 || p < NP) {
+        const char* s = src[u] + (long)t * RB;
+        if (t == nk - 1 && tailz[u]) s = g.zero;
+        // A pieces fill [0, SA), B pieces [SA, STG) (in REG mode the A region is written by ds_write instead)
+        __builtin_amdgcn_global_load_lds((sp_gptr)s, (sp_lptr)(smem + buf * STG + (SA - PA * 1024) + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- REG A loader: chunk c = tid + NT*v -> row c / (2 KS), chunk-in-stage c % (2 KS) ----
+  const char* a_ptr[CPT];
+  const float* s_ptr[CPT];
+  unsigned a_lds[CPT];
+  int a_ch[CPT];
+  sp_f4 ra[CPT][2], rs[CPT][2];
+  if constexpr (AMODE == 1) {
+#pragma unroll
+    for (int v = 0; v < CPT; ++v) {
+      const int c = tid + NT * v;
+      const int row = c / (2 * KS), ch = c % (2 * KS);
+      int m = m0 + row;
+      m = m < g.M ? m : g.M - 1;
+      a_ptr[v] = g.A + (long)m * g.a_rowb + g.a_offb + ch * 32;
+      s_ptr[v] = g.a_scale != nullptr ? g.a_scale + (long)fdiv((uint32_t)m, g.d_hw) * g.K + ch * 8 : nullptr;
+      const int sw = KS == 2 ? (row >> 1) & 7 : (row >> 2) & 3;
+      a_lds[v] = (unsigned)(row * RB + (((2 * ch) ^ sw) << 4));  // hi piece; the lo piece sits at ^16
+      a_ch[v] = ch;
+    }
+  }
+  auto loadA = [&](int t) {
+    if constexpr (AMODE == 1) {
+#pragma unroll
+      for (int v = 0; v < CPT; ++v) {
+        const bool ok = !ktail || (t * 2 * KS + a_ch[v]) < kchunks;
+        const sp_f4 z = {0.f, 0.f, 0.f, 0.f};
+        ra[v][0] = ra[v][1] = z;
+        rs[v][0] = rs[v][1] = z;
+        if (ok) {
+          const sp_f4* p = reinterpret_cast<const sp_f4*>(a_ptr[v] + (long)t * RB);
+          ra[v][0] = p[0], ra[v][1] = p[1];
+          if (g.a_scale != nullptr) {
+            const sp_f4* q = reinterpret_cast<const sp_f4*>(s_ptr[v] + t * 16 * KS);
+            rs[v][0] = q[0], rs[v][1] = q[1];
+          }
+        }
+      }
+    }
+  };
+  auto storeA = [&](int buf) {
+    if constexpr (AMODE == 1) {
+#pragma unroll
+      for (int v = 0; v < CPT; ++v) {
+        sp_h8 hi, lo;
+        if (g.a_scale != nullptr)
+          sp8_split8(ra[v][0] * rs[v][0], ra[v][1] * rs[v][1], hi, lo);
+        else
+          sp8_split8(ra[v][0], ra[v][1], hi, lo);
+        char* const d = smem + buf * STG;
+        *reinterpret_cast<sp_h8*>(d + a_lds[v]) = hi;
+        *reinterpret_cast<sp_h8*>(d + (a_lds[v] ^ 16u)) = lo;
+      }
+    }
+  };
+
+  spf16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const int swr = KS == 2 ? (r >> 1) & 7 : (r >> 2) & 3;
+  unsigned a_off[TM], b_off[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_off[i] = (unsigned)((wm * TM * 32 + i * 32 + r) * RB);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_off[j] = (unsigned)(SA + (wn * TN * 32 + j * 32 + r) * RB);
+
+  // a wave whose rows all lie beyond M (ragged last tile, tiny-M problems) skips its MFMAs
+  const bool wave_active = m0 + wm * TM * 32 < g.M;
+
+  issue(0, 0);
+  loadA(0);
+  storeA(0);
+  int buf = 0;
+  for (int t = 0; t < nk; ++t) {
+    // stage t landed: this wave's DMA pieces (vmcnt) and REG-mode ds_writes (lgkmcnt), then everyone's (barrier).
+    // The barrier also says every wave has finished reading the other buffer, which is refilled next.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nk) {
+      issue(t + 1, buf ^ 1);
+      loadA(t + 1);
+    }
+    if (wave_active) {
+      const char* const sb = smem + buf * STG;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const unsigned shi = (unsigned)(((ks * 4 + h * 2 + 0) ^ swr) << 4);
+        const unsigned slo = (unsigned)(((ks * 4 + h * 2 + 1) ^ swr) << 4);
+        sp_h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + shi);
+          al[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + slo);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + shi);
+          bl[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {  // small cross terms first, the hi*hi product last
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+    if (t + 1 < nk) storeA(buf ^ 1);
+    buf ^= 1;
+  }
+
+  // ---- epilogue ----
+  auto activate = [&](float x) -> float {
+    if constexpr (ACT == ACT_NONE) return x;
+    else if constexpr (ACT == ACT_GELU) return act_gelu(x);
+    else if constexpr (ACT == ACT_MISH) return act_mish(x);
+    else if constexpr (ACT == ACT_SILU) return act_silu(x);
+    else return apply_act(x, g.act);
+  };
+  __builtin_amdgcn_s_barrier();  // every wave is done with the ring: it becomes the store staging area
+  if (!wave_active) return;
+
+  constexpr int SROW = 128 * TN;   // bytes per staged row (32*TN floats)
+  constexpr int PPR = 8 * TN;      // 16-byte pieces per staged row
+  constexpr int WREG = 34 * SROW;  // per wave: 32 staged rows + one row of column scales + one row of biases
+  static_assert(NW * WREG <= 2 * STG, "the store staging area must fit into the ring");
+  char* const stg = smem + wave * WREG;
+  const int nw0 = n0 + wn * TN * 32;  // first column of this wave
+
+  // per-column constants through LDS (register group gq of column block j holds n = nw0 + 32 j + 8 gq + 4 h + 0..3;
+  // keeping all of them in registers beside the accumulators spills on the wide tiles)
+  float* const cst = reinterpret_cast<float*>(stg + 32 * SROW);
+  if (lane < PPR) {
+    const int n = nw0 + lane * 4;
+    sp_f4 w1 = {1.f, 1.f, 1.f, 1.f}, b0 = {0.f, 0.f, 0.f, 0.f};
+    if (n < g.N) {
+      if (g.wscale != nullptr) w1 = *reinterpret_cast<const sp_f4*>(g.wscale + n);
+      if (g.bias != nullptr) b0 = *reinterpret_cast<const sp_f4*>(g.bias + n);
+    }
+    *reinterpret_cast<sp_f4*>(cst + lane * 4) = w1;
+    *reinterpret_cast<sp_f4*>(cst + 32 * TN + lane * 4) = b0;
+  }
+
+  const int mw0 = m0 + wm * TM * 32;  // first row of this wave
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const sp_f4 wsc = *reinterpret_cast<const sp_f4*>(cst + j * 32 + gq * 8 + 4 * h);
+        const sp_f4 bsv = *reinterpret_cast<const sp_f4*>(cst + 32 * TN + j * 32 + gq * 8 + 4 * h);
+        sp_f4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = activate(acc[i][j][4 * gq + e] * wsc[e] + bsv[e]);
+          acc[i][j][4 * gq + e] = v[e];
+        }
+        const int slot = j * 8 + gq * 2 + h;
+        *reinterpret_cast<sp_f4*>(stg + r * SROW + ((slot ^ (r & 7)) << 4)) = v;
+        __builtin_amdgcn_sched_barrier(0);  // one register group at a time: interleaving all of them spills on wide tiles
+      }
+    // the slab is complete in LDS (same wave wrote it; LDS operations of one wave execute in order)
+#pragma unroll
+    for (int it = 0; it < 4 * TN; ++it) {
+      const int pidx = it * 64 + lane;
+      const int row = pidx / PPR, slot = pidx % PPR;
+      sp_f4 v = *reinterpret_cast<const sp_f4*>(stg + row * SROW + ((slot ^ (row & 7)) << 4));
+      const int m = mw0 + i * 32 + row, n = nw0 + slot * 4;
+      if (m < g.M && n < g.N) {
+        if (g.res != nullptr) v = v + *reinterpret_cast<const sp_f4*>(g.res + (long)m * g.ldr + n);
+        *reinterpret_cast<sp_f4*>(g.Out + (long)m * g.ldo + g.o_off + n) = v;
+      }
+    }
+  }
+
+  // ---- GRN partial sums of squares over this wave's rows, segmented by image, fixed summation order ----
+  if (g.grn_part != nullptr) {
+    const int m_end = (mw0 + TM * 32 < g.M) ? mw0 + TM * 32 : g.M;
+    const int img_first = (int)fdiv((uint32_t)mw0, g.d_hw);
+    const int img_last = (int)fdiv((uint32_t)(m_end - 1), g.d_hw);
+    int seg[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = mw0 + i * 32 + r;
+      seg[i] = m < g.M ? (int)fdiv((uint32_t)m, g.d_hw) - img_first : -1;
+    }
+    const bool one_image = img_first == img_last && mw0 + TM * 32 <= g.M;
+    const long unit = (long)tile_m * WM + wm;
+    for (int s = 0; s <= img_last - img_first; ++s) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          sp_f4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = acc[i][j][4 * gq + e];
+              sum[e] += (one_image || seg[i] == s) ? v * v : 0.f;
+            }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum[e] = sp_sum32(sum[e]);
+          const int n = nw0 + j * 32 + gq * 8 + 4 * h;
+          if (r == 0 && n < g.N) *reinterpret_cast<sp_f4*>(g.grn_part + (unit * g.segmax + s) * g.N + n) = sum;
+        }
+    }
+  }
+}
+
+}  // namespace mtgv

@@ -6,8 +6,9 @@ namespace mtgv {
 
 // per-row LayerNorm over C contiguous floats (biased variance, eps inside the sqrt):
 // convnextv2.py:150-160 (both data formats are "per pixel over C" once the tensor is NHWC).
+// out_fmt 1: the output rows are written in SP8 (sp8.h) for an LDS-DMA GEMM (C, ldo, o_off multiples of 8)
 void ln_rows_launch(const float* in, int ldi, int i_off, float* out, int ldo, int o_off, const float* w, const float* b,
-                    long rows, int C, float eps, hipStream_t s);
+                    long rows, int C, float eps, hipStream_t s, int out_fmt = 0);
 
 // depthwise 7x7, pad 3, + bias.  w49 is the weight repacked to [49][C] (tap-major).  convnextv2.py:198-200, :214
 void dwconv7_launch(const float* in, const float* w49, const float* bias, float* out, int N, int H, int W, int C,
@@ -16,7 +17,7 @@ void dwconv7_launch(const float* in, const float* w49, const float* bias, float*
 // depthwise 7x7 + bias followed by LayerNorm over C, fused (no un-normalised intermediate in HBM)
 bool dwconv7_ln_supported(int W, int C);
 void dwconv7_ln_launch(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b, float* out,
-                       int N, int H, int W, int C, float eps, hipStream_t s);
+                       int N, int H, int W, int C, float eps, hipStream_t s, int out_fmt = 0);
 
 // (N,C,H,W) f32 -> (N,H,W,Cp) f32, y = x*scale + shift, channels C..Cp-1 zero.  (x*2-1: convnextv2ae.py:257-258)
 void nchw_to_nhwc_launch(const float* in, float* out, int N, int C, int H, int W, int Cp, float scale, float shift,

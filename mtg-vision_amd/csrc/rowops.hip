@@ -1,6 +1,7 @@
 // Bandwidth-bound NHWC kernels.  All are one-pass over HBM with 16-byte accesses per lane
 // where the channel count allows; arithmetic is fp32 throughout.
 #include "rowops.h"
+#include "sp8.h"
 
 namespace mtgv {
 
@@ -10,7 +11,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // LayerNorm over rows.  G lanes cooperate on one row (G = 4..64, power of two),
 // the row is held in registers between the mean, variance and normalise passes.
 // ---------------------------------------------------------------------------
-template <int G, int NV>
+template <int G, int NV, bool SP8>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ in, int ldi, int i_off, float* __restrict__ out,
                                                      int ldo, int o_off, const float* __restrict__ w,
                                                      const float* __restrict__ b, long rows, int C, float eps) {
@@ -53,18 +54,26 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
     if (c4 < c4n) {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4 * 4);
       const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c4 * 4);
-      *reinterpret_cast<f32x4*>(y + c4 * 4) = (v[i] - mean) * rstd * wv + bv;
+      const f32x4 o = (v[i] - mean) * rstd * wv + bv;
+      if (SP8)  // channel quads c4, c4^1 sit in adjacent lanes and are live together (C % 8 == 0)
+        *reinterpret_cast<sp_h8*>(reinterpret_cast<char*>(y) + (c4 >> 1) * 32 + (c4 & 1) * 16) = sp8_piece_from_quad(o, c4);
+      else
+        *reinterpret_cast<f32x4*>(y + c4 * 4) = o;
     }
   }
 }
 
 template <int G, int NV>
 static void ln_go(const float* in, int ldi, int i_off, float* out, int ldo, int o_off, const float* w, const float* b, long rows,
-                  int C, float eps, hipStream_t s) {
+                  int C, float eps, bool sp8, hipStream_t s) {
   const long rpb = 256 / G;
   const long grid = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL((ln_rows_kernel<G, NV>), dim3((unsigned)grid), dim3(256), 0, s, in, ldi, i_off, out, ldo, o_off, w, b, rows,
-                     C, eps);
+  if (sp8)
+    hipLaunchKernelGGL((ln_rows_kernel<G, NV, true>), dim3((unsigned)grid), dim3(256), 0, s, in, ldi, i_off, out, ldo, o_off, w, b,
+                       rows, C, eps);
+  else
+    hipLaunchKernelGGL((ln_rows_kernel<G, NV, false>), dim3((unsigned)grid), dim3(256), 0, s, in, ldi, i_off, out, ldo, o_off, w, b,
+                       rows, C, eps);
 }
 
 // any C / any stride: one wave per row, scalar accesses (odd head widths only)
@@ -94,8 +103,11 @@ __global__ __launch_bounds__(256) void ln_rows_scalar_kernel(const float* __rest
 }
 
 void ln_rows_launch(const float* in, int ldi, int i_off, float* out, int ldo, int o_off, const float* w, const float* b,
-                    long rows, int C, float eps, hipStream_t s) {
+                    long rows, int C, float eps, hipStream_t s, int out_fmt) {
   if (rows <= 0) return;
+  const bool sp8 = out_fmt == 1;
+  if (sp8) MTGV_CHECK(C % 8 == 0 && ldo % 8 == 0 && o_off % 8 == 0 && ldi % 4 == 0 && i_off % 4 == 0, ERR_INVALID,
+                      "layernorm: SP8 output needs C=%d, ldo=%d, o_off=%d multiples of 8", C, ldo, o_off);
   if (C % 4 != 0 || ldi % 4 != 0 || ldo % 4 != 0 || i_off % 4 != 0 || o_off % 4 != 0) {
     hipLaunchKernelGGL(ln_rows_scalar_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, ldi, i_off, out, ldo, o_off, w,
                        b, rows, C, eps);
@@ -107,7 +119,7 @@ void ln_rows_launch(const float* in, int ldi, int i_off, float* out, int ldo, in
   MTGV_CHECK(C <= 64 * 4 * 12, ERR_INVALID, "layernorm: C=%d too wide", C);
   if (rows <= 0) return;
   const int c4 = C / 4;
-#define LN_CASE(G_, NV_) ln_go<G_, NV_>(in, ldi, i_off, out, ldo, o_off, w, b, rows, C, eps, s)
+#define LN_CASE(G_, NV_) ln_go<G_, NV_>(in, ldi, i_off, out, ldo, o_off, w, b, rows, C, eps, sp8, s)
   if (c4 <= 4) LN_CASE(4, 1);
   else if (c4 <= 8) LN_CASE(8, 1);
   else if (c4 <= 16) LN_CASE(16, 1);
@@ -208,7 +220,7 @@ void dwconv7_launch(const float* in, const float* w49, const float* bias, float*
 // per-pixel mean / variance over channels are block-local: partial sums go through LDS in a fixed order
 // (two-pass variance like ln_rows_kernel, deterministic).
 // ---------------------------------------------------------------------------
-template <int TW>
+template <int TW, bool SP8>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ in, const float* __restrict__ w49,
                                                         const float* __restrict__ bias, const float* __restrict__ ln_w,
                                                         const float* __restrict__ ln_b, float* __restrict__ out, int H, int W,
@@ -296,7 +308,12 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     for (int j = 0; j < TW; ++j)
       if (w0 + j < W) {
         const float mean = stat[(sl * TW + j) * 2], rstd = stat[(sl * TW + j) * 2 + 1];
-        *reinterpret_cast<f32x4*>(op + (long)j * C) = (acc[j] - mean) * rstd * wv + bv;
+        const f32x4 o = (acc[j] - mean) * rstd * wv + bv;
+        if (SP8)  // quads c4, c4^1 of a strip are adjacent lanes with the same predicates (C % 8 == 0)
+          *reinterpret_cast<sp_h8*>(reinterpret_cast<char*>(op + (long)j * C - c) + (c4 >> 1) * 32 + (c4 & 1) * 16) =
+              sp8_piece_from_quad(o, c4);
+        else
+          *reinterpret_cast<f32x4*>(op + (long)j * C) = o;
       }
   }
 }
@@ -307,8 +324,9 @@ bool dwconv7_ln_supported(int W, int C) {
 }
 
 void dwconv7_ln_launch(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b, float* out,
-                       int N, int H, int W, int C, float eps, hipStream_t s) {
+                       int N, int H, int W, int C, float eps, hipStream_t s, int out_fmt) {
   MTGV_CHECK(dwconv7_ln_supported(W, C), ERR_INVALID, "dwconv7_ln: unsupported W=%d C=%d", W, C);
+  MTGV_CHECK(out_fmt == 0 || C % 8 == 0, ERR_INVALID, "dwconv7_ln: SP8 output needs C=%d %% 8 == 0", C);
   if (N <= 0) return;
   const int tw = W >= 8 ? 8 : (W >= 4 ? 4 : 2);
   const int nstrips = ceil_div(W, tw);
@@ -317,12 +335,18 @@ void dwconv7_ln_launch(const float* in, const float* w49, const float* bias, con
   const long total_strips = (long)N * H * nstrips;
   const unsigned grid = (unsigned)((total_strips + S - 1) / S);
   const size_t lds = (size_t)(S * tw * c4n + S * tw * 2) * sizeof(float);
-  if (tw == 8)
-    hipLaunchKernelGGL((dwconv7_ln_kernel<8>), dim3(grid), dim3(256), lds, s, in, w49, bias, ln_w, ln_b, out, H, W, C, nstrips, total_strips, S, eps);
-  else if (tw == 4)
-    hipLaunchKernelGGL((dwconv7_ln_kernel<4>), dim3(grid), dim3(256), lds, s, in, w49, bias, ln_w, ln_b, out, H, W, C, nstrips, total_strips, S, eps);
-  else
-    hipLaunchKernelGGL((dwconv7_ln_kernel<2>), dim3(grid), dim3(256), lds, s, in, w49, bias, ln_w, ln_b, out, H, W, C, nstrips, total_strips, S, eps);
+#define DWLN_GO(TW_, SP_) \
+  hipLaunchKernelGGL((dwconv7_ln_kernel<TW_, SP_>), dim3(grid), dim3(256), lds, s, in, w49, bias, ln_w, ln_b, out, H, W, C, nstrips, total_strips, S, eps)
+  if (out_fmt == 1) {
+    if (tw == 8) DWLN_GO(8, true);
+    else if (tw == 4) DWLN_GO(4, true);
+    else DWLN_GO(2, true);
+  } else {
+    if (tw == 8) DWLN_GO(8, false);
+    else if (tw == 4) DWLN_GO(4, false);
+    else DWLN_GO(2, false);
+  }
+#undef DWLN_GO
   HIP_OK(hipGetLastError());
 }
 

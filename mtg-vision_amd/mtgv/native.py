@@ -95,6 +95,7 @@ SIGNATURES = {
     "mtgv_make_cropped": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mtgv_op_linear": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "mtgv_op_linear_ex_part_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "mtgv_op_last_grn_layout": (C.c_int, [c_vp, c_vp]),
     "mtgv_op_linear_ex": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mtgv_op_conv2d": (C.c_int, [c_vp, c_vp, c_vp, c_vp] + [c_i32] * 10 + [c_vp]),
     "mtgv_op_layernorm": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),

@@ -81,9 +81,14 @@ def test_linear_ex_grn_paths_random():
         nv.check(L.mtgv_op_linear_ex(nv.ptr(A), nv.ptr(W), nv.ptr(B), None, nv.ptr(out), m, n, k, 2, hw, None, None, nv.ptr(part), nv.stream()))
         o = out.cpu().double()
         want = (o * o).view(nimg, hw, n).sum(1)
-        bm = 128
+        import ctypes as C
+
+        ur, sm = C.c_int32(0), C.c_int32(0)
+        nv.check(L.mtgv_op_last_grn_layout(C.byref(ur), C.byref(sm)))
+        bm, segmax = ur.value, sm.value  # rows per partial unit depend on the kernel / tile the launch used
+        assert segmax == (bm - 1) // hw + 2
         tiles_m = -(-m // bm)
-        segmax = (bm - 1) // hw + 2
+        assert tiles_m * segmax * n <= nparts
         p = part[: tiles_m * segmax * n].cpu().double().view(tiles_m, segmax, n)
         got = torch.zeros(nimg, n, dtype=torch.float64)
         for t in range(tiles_m):
