@@ -13,7 +13,9 @@ namespace mtgv {
 // instantiation a call is inlined into - a frame's detections are bit-identical alone or inside a batch, although
 // the two cases pick different GEMM tiles (tests/test_gpu_fullsize.py).
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-__device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
+// v_rcp_f32 itself (1 ulp).  __frcp_rn is the correctly rounded reciprocal: hipcc expands it into the full division
+// sequence (2 v_div_scale, v_rcp, 3 v_fma, v_div_fmas, v_div_fixup) - ten instructions per activation.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // nn.GELU() erf form - mtgvision/models/convnextv2.py:192-193
 __device__ __forceinline__ float act_gelu(float x) {
@@ -27,9 +29,10 @@ __device__ __forceinline__ float act_gelu(float x) {
 // 20.0 cut-over as torch's softplus.
 __device__ __forceinline__ float act_mish(float x) {
 #pragma clang fp contract(off)
+  // beyond the cut-over n = e^40 and n + 2 == n in f32: the quotient is 1 to the last ulp, so the clamp alone gives x
   const float e = fast_exp(fminf(x, 20.0f));
   const float n = e * (e + 2.0f);
-  return x > 20.0f ? x : x * n * fast_rcp(n + 2.0f);
+  return x * (n * fast_rcp(n + 2.0f));
 }
 
 // SiLU of the YOLO Conv block (ultralytics Conv.default_act; call site od_export.py:150)

@@ -14,9 +14,9 @@
 // lane-linear, so the swizzle is applied to the per-lane source address (and to the ds_write address in REG mode).
 //
 // MFMA orientation: weights are the first operand, so the accumulator has n on registers and m on lanes - a lane owns
-// one output row and 4 consecutive columns per register group.  The epilogue (wscale, bias, activation in registers;
-// GRN sum(x^2) partials by cross-lane adds) stages each 32-row slab through LDS so that global stores and residual
-// loads are whole 128-byte lines.
+// one output row and 4 consecutive columns per register group.  The epilogue applies wscale, bias and the activation
+// in registers and stages each 32-row slab through LDS, so that global stores and residual loads are whole 128-byte
+// lines; in the read-back a lane keeps the same 4 columns, which makes the GRN sum(x^2) partials lane-local.
 //
 // Products: lo*hi + hi*lo + hi*hi per k16 step into the same accumulator, k ascending: results do not depend on the
 // tile configuration.
@@ -53,16 +53,6 @@ struct SpDev {
 
 typedef const __attribute__((address_space(1))) void* sp_gptr;
 typedef __attribute__((address_space(3))) void* sp_lptr;
-
-// sum over the 32 lanes that share lane>>5 (fixed order), result in every lane of the half
-__device__ __forceinline__ float sp_sum32(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm 1,0,3,2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm 2,3,0,1
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                // lane ^ 16
-  return v;
-}
 
 template <int WM, int WN, int TM, int TN, int KS, int AMODE, int ACT>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g) {
@@ -280,6 +270,33 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   }
 
   const int mw0 = m0 + wm * TM * 32;  // first row of this wave
+
+  // read-back geometry: PPS lanes walk one staged row (PPS = PPR rounded up to a power of two), so a lane keeps the
+  // same 4 columns for the whole tile - its column sums of squares (GRN) need no cross-lane work until the flush
+  constexpr int PPS = PPR <= 8 ? 8 : (PPR <= 16 ? 16 : 32);
+  constexpr int RPI = 64 / PPS, NIT = 32 / RPI;
+  const int slot = lane % PPS, lrow = lane / PPS;
+  const int ncol = nw0 + slot * 4;
+  const bool col_ok = slot < PPR && ncol < g.N;
+
+  const bool grn = g.grn_part != nullptr;
+  const int img_first = grn ? (int)fdiv((uint32_t)mw0, g.d_hw) : 0;
+  const long unit = (long)tile_m * WM + wm;
+  // per-lane element offsets of row mw0 + lrow; every row this lane stores is a wave-uniform number of rows further on
+  const long o_lane = (long)(mw0 + lrow) * g.ldo + g.o_off + ncol;
+  const long r_lane = (long)(mw0 + lrow) * g.ldr + ncol;
+  sp_f4 run = {0.f, 0.f, 0.f, 0.f};  // sum of squares of this lane's columns over the rows of segment run_seg
+  int run_seg = 0;
+  auto flush = [&]() {
+    sp_f4 t = run;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int mask = PPS; mask < 64; mask <<= 1) t[e] += __shfl_xor(t[e], mask);
+    if (lane < PPS && col_ok) *reinterpret_cast<sp_f4*>(g.grn_part + (unit * g.segmax + run_seg) * g.N + ncol) = t;
+    run = sp_f4{0.f, 0.f, 0.f, 0.f};
+  };
+
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -290,61 +307,59 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
         const sp_f4 bsv = *reinterpret_cast<const sp_f4*>(cst + 32 * TN + j * 32 + gq * 8 + 4 * h);
         sp_f4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = activate(acc[i][j][4 * gq + e] * wsc[e] + bsv[e]);
-          acc[i][j][4 * gq + e] = v[e];
-        }
-        const int slot = j * 8 + gq * 2 + h;
-        *reinterpret_cast<sp_f4*>(stg + r * SROW + ((slot ^ (r & 7)) << 4)) = v;
+        for (int e = 0; e < 4; ++e)  // wsc is a power of two: the fused form rounds exactly like multiply-then-add
+          v[e] = activate(__builtin_fmaf(acc[i][j][4 * gq + e], wsc[e], bsv[e]));
+        const int sl = j * 8 + gq * 2 + h;
+        *reinterpret_cast<sp_f4*>(stg + r * SROW + ((sl ^ (r & 7)) << 4)) = v;
         __builtin_amdgcn_sched_barrier(0);  // one register group at a time: interleaving all of them spills on wide tiles
       }
     // the slab is complete in LDS (same wave wrote it; LDS operations of one wave execute in order)
+    const int ms0 = mw0 + i * 32;
+    int seg_lo = 0, seg_hi = 0;
+    if (grn && ms0 < g.M) {
+      const int m_last = ms0 + 31 < g.M ? ms0 + 31 : g.M - 1;
+      seg_lo = (int)fdiv((uint32_t)ms0, g.d_hw) - img_first;
+      seg_hi = (int)fdiv((uint32_t)m_last, g.d_hw) - img_first;
+    }
+    const bool single = seg_lo == seg_hi;
+    if (grn && single && seg_lo != run_seg) {
+      flush();
+      run_seg = seg_lo;
+    }
 #pragma unroll
-    for (int it = 0; it < 4 * TN; ++it) {
-      const int pidx = it * 64 + lane;
-      const int row = pidx / PPR, slot = pidx % PPR;
-      sp_f4 v = *reinterpret_cast<const sp_f4*>(stg + row * SROW + ((slot ^ (row & 7)) << 4));
-      const int m = mw0 + i * 32 + row, n = nw0 + slot * 4;
-      if (m < g.M && n < g.N) {
-        if (g.res != nullptr) v = v + *reinterpret_cast<const sp_f4*>(g.res + (long)m * g.ldr + n);
-        *reinterpret_cast<sp_f4*>(g.Out + (long)m * g.ldo + g.o_off + n) = v;
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + lrow;
+      const int m = ms0 + row;
+      if (col_ok && m < g.M) {
+        sp_f4 v = *reinterpret_cast<const sp_f4*>(stg + row * SROW + ((slot ^ (row & 7)) << 4));
+        if (grn && single) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) run[e] = __builtin_fmaf(v[e], v[e], run[e]);
+        }
+        const long drow = i * 32 + it * RPI;  // compile-time constant: drow * ld is scalar arithmetic
+        if (g.res != nullptr) v = v + *reinterpret_cast<const sp_f4*>(g.res + r_lane + drow * g.ldr);
+        *reinterpret_cast<sp_f4*>(g.Out + o_lane + drow * g.ldo) = v;
+      }
+    }
+    if (grn && !single) {  // the slab straddles images: one masked pass over the staged slab per image
+      for (int sgm = seg_lo; sgm <= seg_hi; ++sgm) {
+        if (sgm != run_seg) {
+          flush();
+          run_seg = sgm;
+        }
+        for (int it = 0; it < NIT; ++it) {
+          const int row = it * RPI + lrow;
+          const int m = ms0 + row;
+          if (col_ok && m < g.M && (int)fdiv((uint32_t)m, g.d_hw) - img_first == sgm) {
+            const sp_f4 v = *reinterpret_cast<const sp_f4*>(stg + row * SROW + ((slot ^ (row & 7)) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) run[e] = __builtin_fmaf(v[e], v[e], run[e]);
+          }
+        }
       }
     }
   }
-
-  // ---- GRN partial sums of squares over this wave's rows, segmented by image, fixed summation order ----
-  if (g.grn_part != nullptr) {
-    const int m_end = (mw0 + TM * 32 < g.M) ? mw0 + TM * 32 : g.M;
-    const int img_first = (int)fdiv((uint32_t)mw0, g.d_hw);
-    const int img_last = (int)fdiv((uint32_t)(m_end - 1), g.d_hw);
-    int seg[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = mw0 + i * 32 + r;
-      seg[i] = m < g.M ? (int)fdiv((uint32_t)m, g.d_hw) - img_first : -1;
-    }
-    const bool one_image = img_first == img_last && mw0 + TM * 32 <= g.M;
-    const long unit = (long)tile_m * WM + wm;
-    for (int s = 0; s <= img_last - img_first; ++s) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          sp_f4 sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float v = acc[i][j][4 * gq + e];
-              sum[e] += (one_image || seg[i] == s) ? v * v : 0.f;
-            }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sum[e] = sp_sum32(sum[e]);
-          const int n = nw0 + j * 32 + gq * 8 + 4 * h;
-          if (r == 0 && n < g.N) *reinterpret_cast<sp_f4*>(g.grn_part + (unit * g.segmax + s) * g.N + n) = sum;
-        }
-    }
-  }
+  if (grn) flush();
 }
 
 }  // namespace mtgv
