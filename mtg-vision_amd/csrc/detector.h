@@ -18,6 +18,7 @@ struct ConvW {
 struct View {
   float* p = nullptr;
   int H = 0, W = 0, ct = 0, co = 0, C = 0;
+  int fmt = 0;  // 0: f32; 1: SP8 (sp8.h) - same bytes per element, channel offsets in multiples of 8
   View slice(int off, int c) const {
     View v = *this;
     v.co = co + off;
@@ -52,10 +53,11 @@ class Detector {
   ConvW fold(const std::string& prefix, int cin_pad = 0);           // Conv+BN
   ConvW plain(const std::string& prefix);                           // Conv2d with bias
   ConvW concat_out(const std::vector<ConvW>& parts);                // stack along cout
-  float* upload(const std::vector<float>& v);
+  float* upload(const std::vector<float>& v, int row_k = 0);  // row_k > 0: a GEMM B operand with rows of row_k floats
   void conv(const ConvW& w, const View& in, const View& out, int stride, int act, const View* res, int n, hipStream_t s);
   void c2f(int idx, const View& in, const View& out, int n, hipStream_t s);
   View take(int n, int h, int w, int c);
+  View view(const std::string& k) const;
 
   mtgv_detector_cfg cfg_;
   int nm_ = 32, npr_ = 64, reg_max_ = 16, na_ = 0;
@@ -80,6 +82,7 @@ class Detector {
   int* nms_ws_ = nullptr;
   size_t nms_ws_bytes_ = 0;
   int last_n_ = 0;
+  int fmt_ = 0;  // activation format of the forward in progress (0 f32, 1 SP8)
 };
 
 }  // namespace mtgv

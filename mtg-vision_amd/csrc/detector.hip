@@ -6,10 +6,15 @@
 #include "detector.h"
 #include "nms.h"
 #include "rowops.h"
+#include "gemm_sp.h"
+#include "sp8.h"
+#include "act.h"
 
 #include <math.h>
 
 namespace mtgv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static int make_div8(double v) { return (int)(ceil(v / 8.0) * 8.0); }
 static int chn(int c) { return make_div8(std::min(c, 1024) * 0.25); }
@@ -107,6 +112,120 @@ __global__ __launch_bounds__(256) void mask_binarize_kernel(const float* __restr
   const float* L = logits + n * mh * mw;
   const float v = ly0 * (lx0 * L[y0 * mw + x0] + lx1 * L[y0 * mw + x1]) + ly1 * (lx0 * L[y1 * mw + x0] + lx1 * L[y1 * mw + x1]);
   out[idx] = v > 0.f ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// model.0 straight from the uint8 frame: Conv(3 -> 16, k3, s2, p1) + folded BN + SiLU, output SP8 or f32.
+// K = 27 is too short for the matrix cores and the layer is bound by its 16-channel output; a thread computes four
+// neighbouring output pixels x 16 channels with f32 FMAs, weights broadcast from LDS.  Fuses the u8 -> float
+// conversion (img / 255, ultralytics preprocess) that used to be a separate pass over a 4-channel float copy.
+// ---------------------------------------------------------------------------
+template <bool SP8>
+__global__ __launch_bounds__(256) void conv0_u8_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int S, int flip,
+                                                      long total) {
+  __shared__ __attribute__((aligned(16))) float ws[16 * 9 * 4 + 16];  // [o][tap][4] (cin padded to 4) + bias
+  for (int i = threadIdx.x; i < 16 * 9 * 4; i += 256) ws[i] = w[i];
+  if (threadIdx.x < 16) ws[16 * 9 * 4 + threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int OS = S >> 1, OQ = OS >> 2;  // output size, groups of 4 output columns per row
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over n * OS * OQ
+  if (idx >= total) return;
+  const int q = (int)(idx % OQ);
+  const long t = idx / OQ;
+  const int oh = (int)(t % OS);
+  const long n = t / OS;
+  const int ow0 = q * 4;
+  float acc[4][16];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[p][o] = ws[16 * 9 * 4 + o];
+  const int c0 = flip ? 2 : 0, c2 = flip ? 0 : 2;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = 2 * oh - 1 + kh;
+    if (ih < 0 || ih >= S) continue;
+    const uint8_t* const rowp = frames + ((n * S + ih) * (long)S) * 3;
+    float x[9][3];  // input columns 2*ow0-1 .. 2*ow0+7
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int iw = 2 * ow0 - 1 + j;
+      const bool ok = iw >= 0 && iw < S;
+      const uint8_t* const px = rowp + (long)(ok ? iw : 0) * 3;
+      x[j][0] = ok ? __fdiv_rn((float)px[c0], 255.0f) : 0.f;
+      x[j][1] = ok ? __fdiv_rn((float)px[1], 255.0f) : 0.f;
+      x[j][2] = ok ? __fdiv_rn((float)px[c2], 255.0f) : 0.f;
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int o = 0; o < 16; ++o) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[(o * 9 + kh * 3 + kw) * 4]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          float a = acc[p][o];
+          a = __builtin_fmaf(x[2 * p + kw][0], wv[0], a);
+          a = __builtin_fmaf(x[2 * p + kw][1], wv[1], a);
+          a = __builtin_fmaf(x[2 * p + kw][2], wv[2], a);
+          acc[p][o] = a;
+        }
+      }
+  }
+  float* const orow = out + ((n * OS + oh) * (long)OS + ow0) * 16;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x4 v[4];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) v[o >> 2][o & 3] = act_silu(acc[p][o]);
+    if (SP8) {
+      sp_h8 hi, lo;
+      sp8_split8(v[0], v[1], hi, lo);
+      reinterpret_cast<sp_h8*>(orow + p * 16)[0] = hi, reinterpret_cast<sp_h8*>(orow + p * 16)[1] = lo;
+      sp8_split8(v[2], v[3], hi, lo);
+      reinterpret_cast<sp_h8*>(orow + p * 16)[2] = hi, reinterpret_cast<sp_h8*>(orow + p * 16)[3] = lo;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) reinterpret_cast<f32x4*>(orow + p * 16)[k] = v[k];
+    }
+  }
+}
+
+// 5x5 max pool (stride 1, pad 2) on SP8 channel slices: a thread owns one 8-channel chunk, compares hi + lo and keeps
+// the winning pair as it is (no re-rounding)
+__global__ __launch_bounds__(256) void maxpool5_sp8_kernel(const float* __restrict__ in, int ci_total, int ci_off,
+                                                          float* __restrict__ out, int co_total, int co_off, int H, int W, int C,
+                                                          long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over N*H*W*(C/8)
+  if (idx >= total) return;
+  const int c8n = C >> 3;
+  const int c = (int)(idx % c8n) * 8;
+  long t = idx / c8n;
+  const int w = (int)(t % W);
+  t /= W;
+  const int h = (int)(t % H);
+  const long n = t / H;
+  float best[8];
+  sp_h8 bh, bl;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) best[e] = -INFINITY, bh[e] = (_Float16)0.f, bl[e] = (_Float16)0.f;
+  for (int dh = -2; dh <= 2; ++dh) {
+    const int ih = h + dh;
+    if (ih < 0 || ih >= H) continue;
+    for (int dw = -2; dw <= 2; ++dw) {
+      const int iw = w + dw;
+      if (iw < 0 || iw >= W) continue;
+      const sp_h8* const p = reinterpret_cast<const sp_h8*>(in + ((n * H + ih) * W + iw) * ci_total + ci_off + c);
+      const sp_h8 vh = p[0], vl = p[1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (float)vh[e] + (float)vl[e];
+        if (v > best[e]) best[e] = v, bh[e] = vh[e], bl[e] = vl[e];
+      }
+    }
+  }
+  sp_h8* const o = reinterpret_cast<sp_h8*>(out + ((n * H + h) * W + w) * co_total + co_off + c);
+  o[0] = bh, o[1] = bl;
 }
 
 // ---------------------------------------------------------------------------
@@ -218,12 +337,12 @@ int Detector::missing() const {
   return m;
 }
 
-float* Detector::upload(const std::vector<float>& v) {
+float* Detector::upload(const std::vector<float>& v, int row_k) {
   float* d = nullptr;
   HIP_OK(hipMalloc((void**)&d, std::max<size_t>(v.size(), 4) * sizeof(float)));
   HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
   dev_allocs_.push_back(d);
-  gemm_split_register(d, v.size());  // weights become pre-split B operands for the f16x3 GEMMs (small vectors are skipped)
+  gemm_split_register(d, v.size(), row_k);  // weights become pre-split B operands for the f16x3 GEMMs (small vectors are skipped)
   gemm_split_refresh(d, 0, v.size() % 4 == 0 ? v.size() : 0, nullptr);
   HIP_OK(hipStreamSynchronize(nullptr));
   return d;
@@ -248,7 +367,7 @@ ConvW Detector::fold(const std::string& p, int cin_pad) {
           wf[(((size_t)o * k + kh) * k + kw) * cp + i] = (float)((double)w.data[(((size_t)o * cin + i) * k + kh) * k + kw] * sc);
   }
   ConvW c;
-  c.w = upload(wf), c.b = upload(bf), c.cout = cout, c.cin = cp, c.k = k;
+  c.w = upload(wf, k * k * cp), c.b = upload(bf), c.cout = cout, c.cin = cp, c.k = k;
   return c;
 }
 
@@ -262,7 +381,7 @@ ConvW Detector::plain(const std::string& p) {
         for (int kw = 0; kw < k; ++kw)
           wf[(((size_t)o * k + kh) * k + kw) * cin + i] = w.data[(((size_t)o * cin + i) * k + kh) * k + kw];
   ConvW c;
-  c.w = upload(wf), c.b = upload(raw_.at(p + ".bias").data), c.cout = cout, c.cin = cin, c.k = k;
+  c.w = upload(wf, k * k * cin), c.b = upload(raw_.at(p + ".bias").data), c.cout = cout, c.cin = cin, c.k = k;
   return c;
 }
 
@@ -273,6 +392,13 @@ View Detector::take(int n, int h, int w, int c) {
   v.p = arena_.p + arena_used_;
   v.H = h, v.W = w, v.ct = c, v.co = 0, v.C = c;
   arena_used_ += fl;
+  return v;
+}
+
+// activation view by name, in the format of the current forward (fmt_)
+View Detector::view(const std::string& k) const {
+  View v = v_.at(k);
+  v.fmt = (k == "x0" || k == "protos") ? 0 : fmt_;
   return v;
 }
 
@@ -308,7 +434,7 @@ void Detector::finalize() {
       HIP_OK(hipMemcpy(bias.data() + bo, q->b, (size_t)q->cout * sizeof(float), hipMemcpyDeviceToHost));
       wo += (size_t)q->cout * per, bo += q->cout;
     }
-    head_first_[l].w = upload(w), head_first_[l].b = upload(bias);
+    head_first_[l].w = upload(w, (int)per), head_first_[l].b = upload(bias);
     head_first_[l].cout = a.cout + b.cout + c.cout, head_first_[l].cin = a.cin, head_first_[l].k = 3;
     head_box2_[l] = cw_.at(H + ".cv2." + ls + ".1");
     head_cls2_[l] = cw_.at(H + ".cv3." + ls + ".1");
@@ -333,7 +459,7 @@ void Detector::finalize() {
         for (int o = 0; o < co; ++o)
           for (int i = 0; i < ci; ++i) m[(size_t)o * ci + i] = w.data[(((size_t)i * co + o) * 2 + kh) * 2 + kw];
         ConvW c;
-        c.w = upload(m), c.b = bias, c.cout = co, c.cin = ci, c.k = 1;
+        c.w = upload(m, ci), c.b = bias, c.cout = co, c.cin = ci, c.k = 1;
         proto_up_[kh * 2 + kw] = c;
       }
   }
@@ -419,7 +545,8 @@ void Detector::conv(const ConvW& w, const View& in, const View& out, int stride,
   g.OH = out.H, g.OW = out.W, g.OH2 = out.H, g.OW2 = out.W;
   g.ldo = out.ct, g.o_off = out.co;
   g.act = act;
-  if (res) g.res = res->p + res->co, g.ldr = res->ct;
+  g.a_fmt = in.fmt, g.out_fmt = out.fmt;
+  if (res) g.res = res->p + res->co, g.ldr = res->ct, g.res_fmt = res->fmt;
   if (count_flops_) {
     // model.0 is stored with a zero 4th input channel; count the real 3
     const double kk = (&w == &cw_.at("model.0")) ? 27.0 : (double)g.K;
@@ -434,8 +561,8 @@ void Detector::c2f(int idx, const View& in, const View& out, int n, hipStream_t 
   const C2fInfo& ci = c2f_.at(idx);
   const int ch = ci.cout / 2;
   const std::string P = "model." + std::to_string(idx);
-  const View cat = v_.at("cat" + std::to_string(idx));
-  const View tmp = v_.at("tmp" + std::to_string(idx));
+  const View cat = view("cat" + std::to_string(idx));
+  const View tmp = view("tmp" + std::to_string(idx));
   conv(cw_.at(P + ".cv1"), in, cat.slice(0, 2 * ch), 1, ACT_SILU, nullptr, n, s);
   for (int j = 0; j < ci.n; ++j) {
     const View src = cat.slice((1 + j) * ch, ch);
@@ -457,10 +584,26 @@ void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float
   }
   const int S = cfg_.imgsz;
   const int c64 = chn(256), c128 = chn(512), c256 = chn(1024);
-  auto V = [&](const char* k) -> const View& { return v_.at(k); };
+  // f16x3 on the LDS-DMA kernel: every intermediate activation is kept in SP8; the frame, the raw head rows and the
+  // prototypes (decode / mask inputs) stay f32
+  fmt_ = (!count_flops_ && gemm_sp_active()) ? 1 : 0;
+  auto V = [&](const char* k) -> View { return view(k); };
 
-  if (!count_flops_) u8_to_f32_launch(frames, V("x0").p, (long)n * S * S, 3, 4, 1.0f, 0.0f, flip, s);
-  conv(cw_.at("model.0"), V("x0"), V("l0"), 2, ACT_SILU, nullptr, n, s);
+  if (fmt_ == 1 || (!count_flops_ && (S / 2) % 4 == 0 && getenv("MTGV_CONV0_GEMM") == nullptr)) {
+    // model.0 on its own kernel, straight from the uint8 frame
+    const ConvW& w0 = cw_.at("model.0");
+    const View l0 = V("l0");
+    const long total = (long)n * (S / 2) * (S / 8);
+    MTGV_CHECK((S / 2) % 4 == 0 && w0.cout == 16 && w0.cin == 4 && w0.k == 3, ERR_RUNTIME, "detector: unexpected model.0 geometry");
+    if (fmt_ == 1)
+      hipLaunchKernelGGL((conv0_u8_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, w0.w, w0.b, l0.p, S, flip, total);
+    else
+      hipLaunchKernelGGL((conv0_u8_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, w0.w, w0.b, l0.p, S, flip, total);
+    HIP_OK(hipGetLastError());
+  } else {
+    if (!count_flops_) u8_to_f32_launch(frames, V("x0").p, (long)n * S * S, 3, 4, 1.0f, 0.0f, flip, s);
+    conv(cw_.at("model.0"), V("x0"), V("l0"), 2, ACT_SILU, nullptr, n, s);
+  }
   conv(cw_.at("model.1"), V("l0"), V("l1"), 2, ACT_SILU, nullptr, n, s);
   c2f(2, V("l1"), V("l2"), n, s);
   conv(cw_.at("model.3"), V("l2"), V("l3"), 2, ACT_SILU, nullptr, n, s);
@@ -476,7 +619,16 @@ void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float
   const int ch = c256 / 2;
   conv(cw_.at("model.9.cv1"), V("l8"), spp.slice(0, ch), 1, ACT_SILU, nullptr, n, s);
   if (!count_flops_)
-    for (int i = 0; i < 3; ++i) maxpool5_launch(spp.p, spp.ct, i * ch, spp.p, spp.ct, (i + 1) * ch, n, spp.H, spp.W, ch, s);
+    for (int i = 0; i < 3; ++i) {
+      if (fmt_ == 1) {
+        const long total = (long)n * spp.H * spp.W * (ch / 8);
+        hipLaunchKernelGGL(maxpool5_sp8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, spp.p, spp.ct, i * ch, spp.p,
+                           spp.ct, (i + 1) * ch, spp.H, spp.W, ch, total);
+        HIP_OK(hipGetLastError());
+      } else {
+        maxpool5_launch(spp.p, spp.ct, i * ch, spp.p, spp.ct, (i + 1) * ch, n, spp.H, spp.W, ch, s);
+      }
+    }
   const View n9 = V("cat20").slice(c128, c256);     // concat 20 = [19, 9]
   conv(cw_.at("model.9.cv2"), spp, n9, 1, ACT_SILU, nullptr, n, s);
   // top-down
@@ -520,6 +672,7 @@ void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float
       g.OH = in.H, g.OW = in.W;
       g.os = 2, g.oy = q >> 1, g.ox = q & 1, g.OH2 = out.H, g.OW2 = out.W;
       g.ldo = out.ct;
+      g.a_fmt = in.fmt, g.out_fmt = out.fmt;
       if (count_flops_)
         flops_ += 2.0 * g.M * g.N * g.K;
       else

@@ -20,8 +20,10 @@ struct GemmArgs {
   // (same byte layout, so the same offsets address it).  gemm_launch fills it in for registered weights.
   const float* W_split = nullptr;
   float* Out = nullptr;
+  int out_fmt = 0;              // 0: f32; 1: SP8 (LDS-DMA kernel only)
   const float* bias = nullptr;  // [N] or null
   const float* res = nullptr;   // residual [M][ldr] or null
+  int res_fmt = 0;              // format of the residual rows (0 f32, 1 SP8)
   int M = 0, N = 0, K = 0;
 
   // A gather geometry (1x1/linear: KH=KW=1, stride=1, pad=0, H*W = rows per image)

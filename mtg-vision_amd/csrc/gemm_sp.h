@@ -21,6 +21,8 @@ struct SpPlan {
   int tiles_m = 0, tiles_n = 0;
 };
 
+// f16x3 operand mode with the LDS-DMA kernel enabled (MTGV_GEMM_SP != 0): executors then keep activations in SP8
+bool gemm_sp_active();
 // Can (and should) this launch run on the SP kernel?  a.a_fmt says how A is stored.
 SpPlan gemm_sp_plan(const GemmArgs& a);
 // true when a dense [M][K] x [N][K]^T launch with these sizes would take SP8 activations (producer kernels ask before

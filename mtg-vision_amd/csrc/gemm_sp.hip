@@ -138,20 +138,27 @@ bool sp8_lookup(const float* W, int K, const char** sp8, const float** wscale) {
 }
 
 // ---------------------------------------------------------------------------
-// tile configurations
+// tile configurations (one translation unit each: gemm_sp_c<id>.hip)
 // ---------------------------------------------------------------------------
+void gemm_sp_launch_cfg0(const SpDev& g, int amode, hipStream_t s);
+void gemm_sp_launch_cfg1(const SpDev& g, int amode, hipStream_t s);
+void gemm_sp_launch_cfg2(const SpDev& g, int amode, hipStream_t s);
+void gemm_sp_launch_cfg3(const SpDev& g, int amode, hipStream_t s);
+void gemm_sp_launch_cfg4(const SpDev& g, int amode, hipStream_t s);
+
 namespace {
 struct SpCfg {
   int wm, wn, tm, tn;
-  double eff;  // relative MFMA efficiency of the tile (fitted to tools/gemm_sp_sweep.py)
+  double eff;  // relative efficiency of the tile's main loop (fitted to tools/gemm_sp_sweep.py)
   int bm() const { return 32 * tm * wm; }
   int bn() const { return 32 * tn * wn; }
 };
-constexpr int KS_ = 2;
 const SpCfg kCfg[] = {
     {2, 2, 2, 2, 0.93},  // 128 x 128
     {2, 2, 2, 3, 1.00},  // 128 x 192
     {4, 1, 1, 3, 0.88},  // 128 x  96
+    {4, 1, 1, 2, 0.80},  // 128 x  64
+    {4, 1, 1, 1, 0.62},  // 128 x  32
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -163,10 +170,14 @@ bool sp_enabled() {
   }
   return on != 0;
 }
+
+bool is_conv(const GemmArgs& a) { return !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.stride_w <= 1 && a.pad == 0); }
 }  // namespace
 
+bool gemm_sp_active() { return sp_enabled() && gemm_precision() == GEMM_PREC_F16X3; }
+
 bool gemm_sp_takes_sp8(const float* W, int M, int N, int K, int lda, int c_off) {
-  if (!sp_enabled() || gemm_precision() != GEMM_PREC_F16X3) return false;
+  if (!gemm_sp_active()) return false;
   if (K % 8 != 0 || N % 4 != 0 || lda % 8 != 0 || c_off % 8 != 0 || M <= 0) return false;
   return sp8_lookup(W, K, nullptr, nullptr);
 }
@@ -175,16 +186,23 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
   SpPlan pl;
   const bool sp8_in = a.a_fmt == 1;
   auto none = [&]() -> SpPlan {
-    MTGV_CHECK(!sp8_in, ERR_INVALID, "gemm: SP8 activations handed to a launch the SP kernel cannot run");
+    MTGV_CHECK(!sp8_in && a.out_fmt == 0 && a.res_fmt == 0, ERR_INVALID,
+               "gemm: SP8 tensors handed to a launch the SP kernel cannot run (M=%d N=%d K=%d)", a.M, a.N, a.K);
     return pl;
   };
   if (!sp_enabled() || gemm_precision() != GEMM_PREC_F16X3) return none();
-  const bool conv = !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.stride_w <= 1 && a.pad == 0);
+  const bool conv = is_conv(a);
   const bool remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
-  if (conv || remap || a.batch != 1 || a.topk > 0 || a.crop_boxes != nullptr || a.m_count != nullptr) return none();
-  if (a.K % 8 != 0 || a.N % 4 != 0 || a.c_total % 8 != 0 || a.c_off % 8 != 0 || a.ldo % 4 != 0 || a.o_off % 4 != 0 ||
+  if (a.batch != 1 || a.topk > 0 || a.crop_boxes != nullptr || a.m_count != nullptr) return none();
+  if (conv && (!sp8_in || a.stride_w > 0 || a.Cin % 8 != 0)) return none();  // the gather is a DMA-path feature
+  if (remap && !sp8_in) return none();
+  if (a.K % 8 != 0 || a.c_total % 8 != 0 || a.c_off % 8 != 0 || a.ldo % 4 != 0 || a.o_off % 4 != 0 ||
       (a.res != nullptr && a.ldr % 4 != 0))
     return none();
+  // a ragged last column quad is stored element by element: plain f32 outputs only
+  if (a.N % 4 != 0 && (a.out_fmt != 0 || a.res != nullptr || a.grn_part != nullptr || remap)) return none();
+  if (a.out_fmt == 1 && (a.N % 8 != 0 || a.ldo % 8 != 0 || a.o_off % 8 != 0 || a.grn_part != nullptr)) return none();
+  if (a.res != nullptr && a.res_fmt == 1 && (a.ldr % 8 != 0 || a.N % 8 != 0)) return none();
   if (((uintptr_t)a.Out % 16) != 0 || (a.res != nullptr && ((uintptr_t)a.res % 16) != 0)) return none();
   if (sp8_in && a.a_scale != nullptr) return none();
   if (!sp8_lookup(a.W, a.K, nullptr, nullptr)) return none();
@@ -216,35 +234,6 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
   return pl;
 }
 
-template <int WM, int WN, int TM, int TN, int AMODE, int ACT>
-static void sp_launch_one(const SpDev& g, hipStream_t s) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr size_t lds = (size_t)2 * (BM + BN) * 64 * KS_;
-  static bool attr_done = false;
-  auto kern = gemm_sp_kernel<WM, WN, TM, TN, KS_, AMODE, ACT>;
-  if (!attr_done) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * WM * WN), lds, s, g);
-}
-
-template <int WM, int WN, int TM, int TN>
-static void sp_launch_cfg(const SpDev& g, bool sp8_in, hipStream_t s) {
-  if (sp8_in) {
-    switch (g.act) {
-      case ACT_NONE: sp_launch_one<WM, WN, TM, TN, 0, ACT_NONE>(g, s); break;
-      case ACT_MISH: sp_launch_one<WM, WN, TM, TN, 0, ACT_MISH>(g, s); break;
-      case ACT_GELU: sp_launch_one<WM, WN, TM, TN, 0, ACT_GELU>(g, s); break;
-      case ACT_SILU: sp_launch_one<WM, WN, TM, TN, 0, ACT_SILU>(g, s); break;
-      default: sp_launch_one<WM, WN, TM, TN, 0, -1>(g, s); break;
-    }
-  } else {
-    if (g.act == ACT_NONE) sp_launch_one<WM, WN, TM, TN, 1, ACT_NONE>(g, s);
-    else sp_launch_one<WM, WN, TM, TN, 1, -1>(g, s);
-  }
-}
-
 void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   MTGV_CHECK(pl.cfg >= 0 && pl.cfg < kNumCfg, ERR_INVALID, "gemm_sp: no plan");
   SpDev g;
@@ -259,9 +248,11 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   g.bias = a.bias;
   g.res = a.res;
   g.ldr = a.ldr;
+  g.res_fmt = a.res_fmt;
   g.Out = a.Out;
   g.ldo = a.ldo;
   g.o_off = a.o_off;
+  g.out_fmt = a.out_fmt;
   g.M = a.M, g.N = a.N, g.K = a.K;
   g.grn_part = a.grn_part;
   g.hw = a.hw > 0 ? a.hw : 1;
@@ -271,13 +262,22 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   g.zero = zero_page();
   g.tiles_m = pl.tiles_m, g.tiles_n = pl.tiles_n;
   g.act = a.act;
+  g.H = a.H, g.Wd = a.Wd, g.Cin = a.Cin, g.KW = a.KW, g.stride = a.stride, g.pad = a.pad, g.OH = a.OH, g.OW = a.OW;
+  g.d_ohw = make_fastdiv((uint32_t)(a.OH * a.OW));
+  g.d_ow = make_fastdiv((uint32_t)a.OW);
+  g.d_cin = make_fastdiv((uint32_t)(a.Cin > 0 ? a.Cin : 1));
+  g.d_kw = make_fastdiv((uint32_t)a.KW);
+  g.remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
+  g.os = a.os, g.oy = a.oy, g.ox = a.ox, g.OH2 = a.OH2, g.OW2 = a.OW2;
   if (a.grn_part != nullptr)
     MTGV_CHECK(a.segmax >= (pl.unit_rows - 1) / g.hw + 2, ERR_INVALID, "gemm_sp: segmax %d too small", a.segmax);
-  const bool sp8_in = a.a_fmt == 1;
+  const int amode = a.a_fmt == 1 ? (is_conv(a) ? 2 : 0) : 1;
   switch (pl.cfg) {
-    case 0: sp_launch_cfg<2, 2, 2, 2>(g, sp8_in, s); break;
-    case 1: sp_launch_cfg<2, 2, 2, 3>(g, sp8_in, s); break;
-    case 2: sp_launch_cfg<4, 1, 1, 3>(g, sp8_in, s); break;
+    case 0: gemm_sp_launch_cfg0(g, amode, s); break;
+    case 1: gemm_sp_launch_cfg1(g, amode, s); break;
+    case 2: gemm_sp_launch_cfg2(g, amode, s); break;
+    case 3: gemm_sp_launch_cfg3(g, amode, s); break;
+    case 4: gemm_sp_launch_cfg4(g, amode, s); break;
     default: MTGV_CHECK(false, ERR_INVALID, "gemm_sp: bad cfg %d", pl.cfg);
   }
   HIP_OK(hipGetLastError());
