@@ -33,6 +33,48 @@ MFMA_FLOPS_PER_FLOP = {"f32": 1, "f16x3": 3}  # f16x3 issues three fp16 MFMAs pe
 PEAK_HBM_GBS = 8000.0
 
 
+def group_launches(recs, nprof, precision):
+    """Per-group roofline view of the GEMM launches of one step (records of mtgv_profile_gemm_dump over nprof passes).
+    Groups: pwconv1 (1x1 + activation + GRN partials), pwconv2 (GRN-scaled 1x1 + residual), bank (scores + top-k),
+    det3x3 / det1x1 (detector convolutions), enc_other (stem, downsample, head)."""
+    per = max(1, len(recs) // nprof)
+    # launch order inside one pass: detector, then the encoder (whose first launch is the 4x4 stem), then the bank
+    enc_start = min((i for i, r in enumerate(recs[:per]) if int(r["KH"]) == 4 or int(r["grn"])), default=per)
+    out = {}
+    for i, r in enumerate(recs):
+        j = i % per
+        if int(r["topk"]) > 0:
+            g = "bank"
+        elif int(r["grn"]):
+            g = "pwconv1"
+        elif int(r["apro"]):
+            g = "pwconv2"
+        elif j < enc_start:
+            g = "det3x3" if int(r["KH"]) == 3 else "det1x1"
+        else:
+            g = "enc_other"
+        d = out.setdefault(g, {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
+        d["launches"] += 1
+        d["ms"] += float(r["ms"])
+        d["flop"] += 2.0 * int(r["M"]) * int(r["N"]) * int(r["K"]) * int(r["batch"])
+        d["bytes"] += float(r.get("bytes", 0) or 0)
+    peak = PEAK_MFMA_TFLOPS[precision]
+    mult = MFMA_FLOPS_PER_FLOP[precision]
+    res = {}
+    for g, d in out.items():
+        sec = d["ms"] * 1e-3
+        tf = d["flop"] / sec / 1e12 if sec > 0 else 0.0
+        res[g] = {
+            "launches_per_step": d["launches"] // nprof,
+            "ms_per_step": round(d["ms"] / nprof, 3),
+            "algorithmic_tflops": round(tf, 1),
+            "issued_mfma_frac": round(tf * mult / peak, 4),
+            "compulsory_gbs": round(d["bytes"] / sec / 1e9, 1) if sec > 0 else 0.0,
+            "hbm_frac": round(d["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4) if sec > 0 else 0.0,
+        }
+    return res
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +111,10 @@ def main():
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # MTGV_FORCE_COLLECTIVE=1 under torch.distributed.run --nproc-per-node 1: the sharded match path with its RCCL
+    # all-gathers runs with one rank (rehearsal of the multi-GPU code on a one-GPU box)
+    force_coll = os.environ.get("MTGV_FORCE_COLLECTIVE") == "1" and "RANK" in os.environ
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             try:
@@ -98,7 +143,7 @@ def main():
     encoder = Encoder(enc_cfg, enc_sd, max_batch=F * K)
 
     # bank: rng(2) standard normal, generated in row blocks so that every rank can build just its shard
-    sharded = world > 1 and a.bank_mode == "sharded"
+    sharded = (world > 1 or force_coll) and a.bank_mode == "sharded"
     lo, hi = mdist.shard_rows(a.bank, rank, world) if sharded else (0, a.bank)
     matcher = Matcher(768, capacity=hi - lo, id_base=lo)
     blk = 12_500
@@ -122,22 +167,29 @@ def main():
         match_fn = None
     pipe = Pipeline(detector, encoder, matcher, K, 1, match_fn, quad_source=a.quads)
 
+    # NB distinct synthetic batches rotate through the steps (a single 39 MB batch would stay in the Infinity Cache)
+    NB = 4
     g = torch.Generator(device=dev).manual_seed(4 + rank)
-    frames = torch.randint(0, 256, (F, 640, 640, 3), generator=g, device=dev, dtype=torch.uint8)
+    batches = [torch.randint(0, 256, (F, 640, 640, 3), generator=g, device=dev, dtype=torch.uint8) for _ in range(NB)]
+    frames = batches[0]
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_coll:
             dist.barrier()
         torch.cuda.synchronize()
 
     # every step is one full pass over one batch; with overlap (default) the detect stage of step i+1 runs on a
     # second HIP stream beside the embed/match stages of step i - all K steps start and finish inside the timed region
+    # (opt-in in the library; the bench, which runs only this library's kernels, enables it unless --no-overlap)
+    if not a.no_overlap:
+        os.environ.setdefault("MTGV_OVERLAP", "on")
     overlap = (not a.no_overlap) and pipe.overlap_enabled()
 
     def run_steps(k):
+        seq = [batches[i % NB] for i in range(k)]
         if not overlap:
-            return [pipe.run(frames) for _ in range(k)]
-        return pipe.run_many([frames] * k)
+            return [pipe.run(fr) for fr in seq]
+        return pipe.run_many(seq)
 
     run_steps(a.warmup)
     barrier()
@@ -145,7 +197,7 @@ def main():
     out = run_steps(a.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_coll:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -172,6 +224,7 @@ def main():
             f"-> 192x128 crops -> ConvNeXt-V2 {a.encoder} (z=768) -> cosine top-1 over {a.bank}x768 bank",
             "crop_quads": "detection boxes" if a.quads == "box" else "oriented quads fitted to the detection masks (mask_quads_kernel)",
             "frames_per_gpu": F,
+            "distinct_frame_batches": NB,
             "cards_per_frame": K,
             "bank": [a.bank, 768],
             "bank_layout": ("row-sharded %d-way + RCCL all-gather of per-shard top-1" % world) if sharded else "replicated",
@@ -193,14 +246,25 @@ def main():
     if not a.no_roofline:
         native.check(L.mtgv_profile_gemm(1))
         nprof = 2
-        for _ in range(nprof):
-            pipe.run(frames)
+        for i in range(nprof):
+            pipe.run(batches[i % NB])
         torch.cuda.synchronize()
         ms, fl, nl, by = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_double(0)
         native.check(L.mtgv_profile_gemm_read(C.byref(ms), C.byref(fl), C.byref(nl)))
         native.check(L.mtgv_profile_gemm_bytes(C.byref(by)))
+        groups = None
+        if rank == 0:
+            import csv
+            import tempfile
+
+            with tempfile.NamedTemporaryFile(suffix=".csv", delete=False) as tf:
+                tmp_csv = tf.name
+            native.check(L.mtgv_profile_gemm_dump(tmp_csv.encode()))
+            recs = list(csv.DictReader(open(tmp_csv)))
+            os.unlink(tmp_csv)
+            groups = group_launches(recs, nprof, precision)
         native.check(L.mtgv_profile_gemm(0))
-        prof = (ms.value / nprof, fl.value / nprof, int(nl.value // nprof), by.value / nprof)
+        prof = (ms.value / nprof, fl.value / nprof, int(nl.value // nprof), by.value / nprof, groups)
         barrier()
 
     if rank == 0:
@@ -208,17 +272,19 @@ def main():
         det_flops = detector.flops_per_frame()
         res["config"]["algorithmic_gflop_per_card"] = round((gflops_enc + dw_enc + det_flops / K + 2 * a.bank * 768) / 1e9, 3)
         if prof is not None:
-            gemm_ms, gemm_fl, launches, gemm_bytes = prof
+            gemm_ms, gemm_fl, launches, gemm_bytes, groups = prof
             sec = gemm_ms * 1e-3
             tfl = gemm_fl / sec / 1e12 if sec > 0 else 0.0
             gbs = gemm_bytes / sec / 1e9 if sec > 0 else 0.0
             peak_tf = PEAK_MFMA_TFLOPS[precision]
             issued = tfl * MFMA_FLOPS_PER_FLOP[precision]
-            traffic = None
+            traffic, traffic_src = None, None
             tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")
             if os.path.exists(tfile):
                 try:
-                    traffic = json.load(open(tfile)).get(precision, {}).get("hbm_bytes_per_step")
+                    tj = json.load(open(tfile))
+                    traffic = tj.get(precision, {}).get("hbm_bytes_per_step")
+                    traffic_src = "static: profiles/gemm_traffic.json, collected at %s (not re-measured by this run)" % tj.get("collected_at", "round 1")
                 except Exception:
                     traffic = None
             # which roof binds the kernel: the larger of its two minimum times
@@ -231,13 +297,16 @@ def main():
             top = mfma_view if bound == "mfma" else hbm_view
             res["roofline"] = {
                 "bound": bound,
-                "kernel": "gemm_f32_kernel<..., PREC=%d> (implicit-GEMM conv/linear/bank kernel; all launches of one step)" % (0 if precision == "f32" else 1),
+                "kernel": ("gemm_f32_kernel<..., PREC=0> (implicit-GEMM conv/linear/bank kernel; all launches of one step)" if precision == "f32" else
+                           "split-precision GEMM launches of one step: gemm_sp_kernel (LDS-DMA, SP8 operands) + gemm_f32_kernel<..., PREC=1> (stem, mask and bank launches)"),
                 "achieved": top["achieved"],
                 "peak": top["peak"],
                 "unit": top["unit"],
                 "frac": top["frac"],
                 "traffic": traffic,
-                "traffic_note": "HBM bytes of these launches per step, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/gemm_traffic.json)",
+                "traffic_note": "HBM bytes of these launches per step, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE",
+                "traffic_source": traffic_src,
+                "groups": groups,
                 "launches_per_step": launches,
                 "gemm_ms_per_step": round(gemm_ms, 3),
                 "algorithmic_gflop_per_step": round(gemm_fl / 1e9, 2),
@@ -252,8 +321,20 @@ def main():
             # bounded CPU sample of the same workload on the host cores: the oracle pipeline
             from oracle import pipeline_ref
 
-            nthreads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
+            # every host core this process may run on (the scheduler affinity; os.cpu_count() counts the whole host)
+            try:
+                nthreads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                nthreads = os.cpu_count() or 1
             torch.set_num_threads(nthreads)
+            cpu_model = "unknown"
+            try:
+                for ln in open("/proc/cpuinfo"):
+                    if ln.startswith("model name"):
+                        cpu_model = ln.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
             cf = min(a.cpu_frames, F)
             bank_cpu = matcher.rows(0, len(matcher))
             fr = frames[:cf].cpu().numpy()
@@ -265,12 +346,14 @@ def main():
                 "value": round(cf * K / cdt, 2),
                 "unit": "cards/s",
                 "cores": nthreads,
+                "cpu_model": cpu_model,
+                "host_cpu_count": os.cpu_count(),
                 "kind": "port",
                 "sample": f"{cf} frames x {K} cards of the same synthetic workload through oracle/pipeline_ref.py "
                 f"(PyTorch CPU fp32, {nthreads} threads), {cdt:.1f} s",
             }
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_coll:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -2,6 +2,10 @@
 // Detector / NMS / warp entry points live next to their kernels (detector.hip, nms.hip, warp.hip).
 #include "mtgv.h"
 
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+
 #include "encoder.h"
 #include "match.h"
 #include "rowops.h"
@@ -33,6 +37,36 @@ struct ScopedWeights {
   }
 };
 thread_local GrnLayout t_last_grn;
+
+// max |x| of a device tensor (test / composition surface: one small kernel + a host read)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+
+// A power of two that brings an activation tensor into the fp16 range of the split GEMM (1 when it already is):
+// the single-op entry points take arbitrary f32 data, the handles know their activations are LayerNorm outputs etc.
+void range_guard(GemmArgs& g, const float* a_dev, long n, hipStream_t s) {
+  if (gemm_precision() != GEMM_PREC_F16X3 || n <= 0) return;
+  static unsigned* d_max = nullptr;
+  if (d_max == nullptr) HIP_OK(hipMalloc((void**)&d_max, sizeof(unsigned)));
+  HIP_OK(hipMemsetAsync(d_max, 0, sizeof(unsigned), s));
+  const unsigned grid = (unsigned)std::min<long>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, a_dev, n, d_max);
+  unsigned bits = 0;
+  HIP_OK(hipMemcpyAsync(&bits, d_max, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  float mx;
+  memcpy(&mx, &bits, sizeof(float));
+  if (!(mx > 16384.0f) || !(mx < INFINITY)) return;
+  int ex;
+  (void)frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1): scaled maximum lands in [2^13, 2^14)
+  g.a_mul = ldexpf(1.0f, 14 - ex);
+  g.a_unmul = ldexpf(1.0f, ex - 14);
+}
 }  // namespace
 
 struct mtgv_encoder {
@@ -194,6 +228,7 @@ MTGV_API int mtgv_op_linear(const float* a_dev, const float* w_dev, const float*
     GemmArgs g = linear_args(a_dev, k, w_dev, bias_dev, out_dev, n, m, n, k, act);
     g.res = res_dev;
     g.ldr = n;
+    range_guard(g, a_dev, (long)m * k, (hipStream_t)stream);
     gemm_launch(g, gemm_plan(m, n, k, act != 0), (hipStream_t)stream);
   });
 }

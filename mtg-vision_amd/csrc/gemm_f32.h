@@ -19,6 +19,11 @@ struct GemmArgs {
   // f16x3 only, optional: W with every aligned group of 4 floats replaced by their 4 fp16 hi + 4 fp16 lo halves
   // (same byte layout, so the same offsets address it).  gemm_launch fills it in for registered weights.
   const float* W_split = nullptr;
+  // per-column power-of-two scales of W_split (registered rows are stored scaled, gemm_sp.h); filled in by gemm_launch
+  const float* wscale = nullptr;
+  // f16x3 only: A is multiplied by a_mul (a power of two) before it is split and the accumulator by a_unmul = 1/a_mul.
+  // For launches whose activations may exceed the fp16 range (|a| > 65504); 1 everywhere on the recognition path.
+  float a_mul = 1.0f, a_unmul = 1.0f;
   float* Out = nullptr;
   int out_fmt = 0;              // 0: f32; 1: SP8 (LDS-DMA kernel only)
   const float* bias = nullptr;  // [N] or null

@@ -37,7 +37,7 @@ struct GemmProf {
   double flops = 0;
   double bytes = 0;  // compulsory HBM bytes: every operand element read once, every output written once
   long launches = 0;
-  struct Rec { int M, N, K, KH, stride, batch, act, apro, grn, topk; };
+  struct Rec { int M, N, K, KH, stride, batch, act, apro, grn, topk, sp; double bytes; };
   std::vector<Rec> recs;
 } g_prof;
 }  // namespace
@@ -55,7 +55,7 @@ void gemm_profile_enable(bool on) {
 void gemm_profile_dump(const char* path) {
   FILE* f = fopen(path, "w");
   MTGV_CHECK(f != nullptr, ERR_RUNTIME, "cannot open %s", path);
-  fprintf(f, "idx,M,N,K,KH,stride,batch,act,apro,grn,topk,tm,tn,bk,ms,tflops\n");
+  fprintf(f, "idx,M,N,K,KH,stride,batch,act,apro,grn,topk,tm,tn,bk,ms,tflops,bytes,sp\n");
   for (size_t i = 0; i + 1 < g_prof.used && i / 2 < g_prof.recs.size(); i += 2) {
     HIP_OK(hipEventSynchronize(g_prof.ev[i + 1]));
     float t = 0.f;
@@ -63,8 +63,8 @@ void gemm_profile_dump(const char* path) {
     const auto& r = g_prof.recs[i / 2];
     const GemmPlan pl = r.topk ? GemmPlan{1, 2, 16, 0, 0} : gemm_plan(r.M, r.N, r.K, r.act != 0, r.apro != 0);
     const double fl = 2.0 * r.M * r.N * r.K * r.batch;
-    fprintf(f, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f\n", i / 2, r.M, r.N, r.K, r.KH, r.stride, r.batch, r.act,
-            r.apro, r.grn, r.topk, pl.tm, pl.tn, pl.bk, t, fl / (t * 1e-3) / 1e12);
+    fprintf(f, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f,%.0f,%d\n", i / 2, r.M, r.N, r.K, r.KH, r.stride, r.batch, r.act,
+            r.apro, r.grn, r.topk, pl.tm, pl.tn, pl.bk, t, fl / (t * 1e-3) / 1e12, r.bytes, r.sp);
   }
   fclose(f);
 }
@@ -85,7 +85,7 @@ void gemm_profile_read(double* ms, double* flops, long* launches) {
   if (launches) *launches = g_prof.launches;
 }
 
-static void prof_begin(const GemmArgs& a, hipStream_t s) {
+static void prof_begin(const GemmArgs& a, hipStream_t s, int sp = 0) {
   if (!g_prof.on) return;
   while (g_prof.ev.size() < g_prof.used + 2) {
     hipEvent_t e;
@@ -100,11 +100,12 @@ static void prof_begin(const GemmArgs& a, hipStream_t s) {
     const double w_el = (double)a.N * a.K;
     const double o_el = a.topk > 0 ? (double)a.M * ceil_div(a.N, 64) * a.topk * 2 : (double)a.M * a.N;
     const double r_el = a.res != nullptr ? (double)a.M * a.N : 0.0;
-    g_prof.bytes += 4.0 * ((a.strideA != 0 || a.batch == 1 ? a.batch : 1) * a_el + (a.strideW != 0 || a.batch == 1 ? a.batch : 1) * w_el +
-                           a.batch * (o_el + r_el));
+    const double by = 4.0 * ((a.strideA != 0 || a.batch == 1 ? a.batch : 1) * a_el + (a.strideW != 0 || a.batch == 1 ? a.batch : 1) * w_el +
+                             a.batch * (o_el + r_el));
+    g_prof.bytes += by;
+    g_prof.recs.push_back({a.M, a.N, a.K, a.KH, a.stride, a.batch, a.act, a.a_scale != nullptr, a.grn_part != nullptr, a.topk, sp, by});
   }
   g_prof.launches += 1;
-  g_prof.recs.push_back({a.M, a.N, a.K, a.KH, a.stride, a.batch, a.act, a.a_scale != nullptr, a.grn_part != nullptr, a.topk});
 }
 static void prof_end(hipStream_t s) {
   if (!g_prof.on) return;
@@ -126,10 +127,25 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
   reinterpret_cast<f16x8*>(out)[i] = o;
 }
 
+// rows of row_k floats, stored scaled by 1 / wscale[row] (the power of two the SP8 copy of the same buffer uses)
+__global__ __launch_bounds__(256) void split_pack_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             const float* __restrict__ wscale, long n4, int rk4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float sc = 1.0f / wscale[i / rk4];  // exact: wscale is a power of two
+  f16x4 hi, lo;
+  split_f16(reinterpret_cast<const f32x4*>(in)[i] * sc, hi, lo);
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = hi[j], o[4 + j] = lo[j];
+  reinterpret_cast<f16x8*>(out)[i] = o;
+}
+
 namespace {
 struct SplitEntry {
   float* buf = nullptr;
   size_t n = 0;
+  int row_k = 0;  // > 0: rows of row_k floats stored with the per-row scale of the SP8 registry
 };
 std::map<const float*, SplitEntry> g_split;
 std::mutex g_split_mu;
@@ -140,15 +156,21 @@ void gemm_split_register(const float* W, size_t n_floats, int row_k) {
   if (row_k > 0) sp8_register(W, n_floats, row_k);
   std::lock_guard<std::mutex> lk(g_split_mu);
   SplitEntry& e = g_split[W];
-  if (e.buf != nullptr && e.n == n_floats) return;
+  const int rk = (row_k > 0 && row_k % 8 == 0 && n_floats % (size_t)row_k == 0) ? row_k : 0;  // what sp8_register accepts
+  if (e.buf != nullptr && e.n == n_floats) {
+    e.row_k = rk;
+    return;
+  }
   if (e.buf != nullptr) (void)hipFree(e.buf);
   e.n = n_floats;
+  e.row_k = rk;
   HIP_OK(hipMalloc((void**)&e.buf, n_floats * sizeof(float)));
 }
 
 void gemm_split_refresh(const float* W, size_t offset_floats, size_t n_floats, hipStream_t s) {
-  sp8_refresh(W, offset_floats, n_floats, s);
+  sp8_refresh(W, offset_floats, n_floats, s);  // also (re)computes the rows' scales
   float* out = nullptr;
+  int row_k = 0;
   {
     std::lock_guard<std::mutex> lk(g_split_mu);
     auto it = g_split.find(W);
@@ -156,10 +178,19 @@ void gemm_split_refresh(const float* W, size_t offset_floats, size_t n_floats, h
     MTGV_CHECK(offset_floats % 4 == 0 && n_floats % 4 == 0 && offset_floats + n_floats <= it->second.n, ERR_INVALID,
                "split refresh outside the registered buffer");
     out = it->second.buf;
+    row_k = it->second.row_k;
   }
   if (n_floats == 0) return;
   const long n4 = (long)(n_floats / 4);
-  hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W + offset_floats, out + offset_floats, n4);
+  const float* wsc = nullptr;
+  if (row_k > 0) {
+    MTGV_CHECK(offset_floats % row_k == 0 && n_floats % row_k == 0, ERR_INVALID, "split refresh must cover whole rows");
+    MTGV_CHECK(sp8_lookup(W + offset_floats, row_k, nullptr, &wsc), ERR_RUNTIME, "split refresh: row scales missing");
+    hipLaunchKernelGGL(split_pack_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W + offset_floats,
+                       out + offset_floats, wsc, n4, row_k / 4);
+  } else {
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W + offset_floats, out + offset_floats, n4);
+  }
   HIP_OK(hipGetLastError());
 }
 
@@ -176,6 +207,17 @@ const float* gemm_split_lookup(const float* W) {
   std::lock_guard<std::mutex> lk(g_split_mu);
   auto it = g_split.find(W);
   return it == g_split.end() ? nullptr : it->second.buf;
+}
+
+// pre-split copy usable by a launch with rows of K floats: unscaled copies always, scaled ones only with their scales
+static const float* split_for_launch(const float* W, int K, const float** wscale) {
+  *wscale = nullptr;
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  auto it = g_split.find(W);
+  if (it == g_split.end()) return nullptr;
+  if (it->second.row_k == 0) return it->second.buf;
+  if (it->second.row_k != K || !sp8_lookup(W, K, nullptr, wscale)) return nullptr;
+  return it->second.buf;
 }
 
 static int g_prec = -1;  // -1: not read from the environment yet
@@ -289,7 +331,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
     const SpPlan sp = gemm_sp_plan(a);  // the LDS-DMA split kernel takes every launch it can run
     if (sp.cfg >= 0) {
       if (a.grn_part) MTGV_CHECK(a.hw > 0 && a.M % a.hw == 0, ERR_INVALID, "gemm: hw=%d must divide M=%d", a.hw, a.M);
-      prof_begin(a, s);
+      prof_begin(a, s, 1);
       gemm_sp_launch(a, sp, s);
       prof_end(s);
       return;
@@ -299,8 +341,9 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
 
   GemmDev g;
   g.a = a;
-  if (gemm_precision() == GEMM_PREC_F16X3 && g.a.W_split == nullptr && a.strideW == 0) g.a.W_split = gemm_split_lookup(a.W);
-  if (gemm_precision() != GEMM_PREC_F16X3) g.a.W_split = nullptr;
+  if (gemm_precision() == GEMM_PREC_F16X3 && g.a.W_split == nullptr && a.strideW == 0)
+    g.a.W_split = split_for_launch(a.W, a.K, &g.a.wscale);
+  if (gemm_precision() != GEMM_PREC_F16X3) g.a.W_split = nullptr, g.a.wscale = nullptr;
   g.d_ohw = make_fastdiv((uint32_t)(a.OH * a.OW));
   g.d_ow = make_fastdiv((uint32_t)a.OW);
   g.d_cin = make_fastdiv((uint32_t)a.Cin);

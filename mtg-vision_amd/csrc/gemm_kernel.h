@@ -30,7 +30,10 @@ struct GemmDev {
   int off32_ok;  // every operand of the launch spans less than 4 GiB: 32-bit byte offsets are enough
 };
 
-// x = hi + lo + O(2^-22 |x|), both halves fp16, both rounded to nearest (fp16 subnormals are kept by the matrix unit).
+// x = hi + lo + O(2^-22 |x|) while lo is a normal fp16 (|x| >= 2^-3); below that lo is subnormal and the error floor is
+// 2^-25 ABSOLUTE (fp16 subnormals are kept by the matrix unit).  Registered weights therefore carry a power-of-two scale
+// per row (wscale, undone on the f32 accumulator) that puts the row maximum at 2^13..2^14; activations are O(1) per row
+// (LayerNorm outputs, activations, pixels), and a launch whose A may exceed the fp16 range passes a_mul (sp8.h).
 // A truncated hi (mask off 13 mantissa bits, no conversion back to f32) is 1 % faster and as accurate on one GEMM,
 // but its remainder always has the sign of x, so the dropped lo*lo term becomes a systematic bias that adds up over
 // the detector's layers (proto error vs the oracle 1.0e-4 instead of 1.7e-5): rounding it is.
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         f16x4 hi, lo;
-        split_f16(APRO ? ra[i] * rsa[i] : ra[i], hi, lo);
+        split_f16((APRO ? ra[i] * rsa[i] : ra[i]) * p.a_mul, hi, lo);
         const int o = (lrow + i * RPP) * LSH + lk;
         *reinterpret_cast<f16x4*>(&Ah[(buf * 2 + 0) * BM * LSH + o]) = hi;
         *reinterpret_cast<f16x4*>(&Ah[(buf * 2 + 1) * BM * LSH + o]) = lo;
@@ -381,11 +384,11 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const bool nok = (bn0 + j * 32 + col) < p.N;
+      const float ws = (PREC == 1 && p.wscale != nullptr && nok) ? p.wscale[bn0 + j * 32 + col] * p.a_unmul : p.a_unmul;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (!nok) acc[i][j][r] = -INFINITY;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = nok ? acc[i][j][r] * ws : -INFINITY;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -437,9 +440,12 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
     const long row0 = (long)bm0 + (long)wave_u * 32 * TM;
     float* const obase = Op + row0 * p.ldo + p.o_off + bn0;
     const unsigned loff = (unsigned)(4 * half) * (unsigned)p.ldo + (unsigned)col;
-    float bv[TN];
+    float bv[TN], wsv[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bv[j] = p.bias != nullptr ? p.bias[bn0 + j * 32 + col] : 0.f;
+    for (int j = 0; j < TN; ++j) {
+      bv[j] = p.bias != nullptr ? p.bias[bn0 + j * 32 + col] : 0.f;
+      wsv[j] = (PREC == 1 && p.wscale != nullptr) ? p.wscale[bn0 + j * 32 + col] * p.a_unmul : p.a_unmul;
+    }
     if (p.res != nullptr) {
       const float* const rbase = p.res + row0 * p.ldr + bn0;
       const unsigned roff = (unsigned)(4 * half) * (unsigned)p.ldr + (unsigned)col;
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
             const long rr = i * 32 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-              const float v = activate(acc[i][j][r] + bv[j]);
+              const float v = activate(PREC == 1 ? __builtin_fmaf(acc[i][j][r], wsv[j], bv[j]) : acc[i][j][r] + bv[j]);
               (obase + rr * p.ldo + j * 32)[loff] = v + rv[q][j];
               acc[i][j][r] = v;
             }
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
           const long rr = i * 32 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            const float v = activate(acc[i][j][r] + bv[j]);
+            const float v = activate(PREC == 1 ? __builtin_fmaf(acc[i][j][r], wsv[j], bv[j]) : acc[i][j][r] + bv[j]);
             (obase + rr * p.ldo + j * 32)[loff] = v;
             acc[i][j][r] = v;
           }
@@ -490,6 +496,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
       const int n = bn0 + j * 32 + col;
       const bool nok = n < p.N;
       const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+      const float ws = (PREC == 1 && p.wscale != nullptr && nok) ? p.wscale[n] * p.a_unmul : p.a_unmul;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
           const int m = bm0 + wave * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           float v = 0.f;
           if (m < M_eff && nok) {
-            v = activate(acc[i][j][r] + bv);
+            v = activate(PREC == 1 ? __builtin_fmaf(acc[i][j][r], ws, bv) : acc[i][j][r] + bv);
             if (p.crop_boxes != nullptr) {
               const float* bx = p.crop_boxes + ((long)z * p.crop_rows + m) * 4;
               const uint32_t py = fdiv((uint32_t)n, g.d_cw);

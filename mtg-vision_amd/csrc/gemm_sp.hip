@@ -259,6 +259,8 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   g.segmax = a.segmax;
   g.d_hw = make_fastdiv((uint32_t)g.hw);
   g.a_scale = a.a_scale;
+  g.a_mul = a.a_fmt == 1 ? 1.0f : a.a_mul;
+  g.a_unmul = a.a_fmt == 1 ? 1.0f : a.a_unmul;
   g.zero = zero_page();
   g.tiles_m = pl.tiles_m, g.tiles_n = pl.tiles_n;
   g.act = a.act;

@@ -53,6 +53,7 @@ struct SpDev {
   int hw = 1, segmax = 0;
   FastDiv d_hw;
   const float* a_scale = nullptr;  // AMODE 1: [M/hw][K]
+  float a_mul = 1.0f, a_unmul = 1.0f;  // AMODE 1: power-of-two pre-scale of A (range guard) and its inverse
   const char* zero = nullptr;   // >= 16 zero bytes (K tail / padding taps of the DMA paths)
   int tiles_m = 0, tiles_n = 0;
   int act = 0;
@@ -204,9 +205,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
       for (int v = 0; v < CPT; ++v) {
         sp_h8 hi, lo;
         if (g.a_scale != nullptr)
-          sp8_split8(ra[v][0] * rs[v][0], ra[v][1] * rs[v][1], hi, lo);
+          sp8_split8(ra[v][0] * rs[v][0] * g.a_mul, ra[v][1] * rs[v][1] * g.a_mul, hi, lo);
         else
-          sp8_split8(ra[v][0], ra[v][1], hi, lo);
+          sp8_split8(ra[v][0] * g.a_mul, ra[v][1] * g.a_mul, hi, lo);
         char* const d = smem + buf * STG;
         *reinterpret_cast<sp_h8*>(d + a_lds[v]) = hi;
         *reinterpret_cast<sp_h8*>(d + (a_lds[v] ^ 16u)) = lo;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
           if (g.bias != nullptr) b0[e] = g.bias[n + e];
         }
     }
-    *reinterpret_cast<sp_f4*>(cst + lane * 4) = w1;
+    *reinterpret_cast<sp_f4*>(cst + lane * 4) = w1 * g.a_unmul;
     *reinterpret_cast<sp_f4*>(cst + 32 * TN + lane * 4) = b0;
   }
 

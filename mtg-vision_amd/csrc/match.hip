@@ -58,7 +58,8 @@ Bank::Bank(int dim, int64_t capacity) : dim_(dim), cap_(capacity) {
   MTGV_CHECK(dim > 0 && dim % 4 == 0, ERR_INVALID, "bank: dim=%d must be a positive multiple of 4", dim);
   MTGV_CHECK(capacity > 0 && capacity < (1ll << 31), ERR_INVALID, "bank: capacity=%lld", (long long)capacity);
   vecs_.alloc((size_t)capacity * dim);
-  gemm_split_register(vecs_.p, (size_t)capacity * dim);  // the bank is the B operand of the match GEMM
+  // the bank is the B operand of the match GEMM; rows of `dim` floats get per-row scaled split copies
+  gemm_split_register(vecs_.p, (size_t)capacity * dim, dim % 8 == 0 ? dim : 0);
 }
 
 Bank::~Bank() { gemm_split_unregister(vecs_.p); }

@@ -6,16 +6,18 @@ local row + offset), top-k of the union = merge of per-shard top-k:
 
     1. all_gather the local query embeddings        (B_local x D fp32 each)
     2. every rank scores ALL queries against its shard, local top-k (ids already global)
-    3. all_gather the (score, id) candidates         (B_total x k pairs per rank)
+    3. all_gather the (id, score) candidates, packed into ONE int64 buffer (B_total x k x 2 per rank)
     4. every rank merges the R*k candidates of its OWN queries (score desc, id asc)
 
-Both messages are KB-scale: latency-bound, xGMI bandwidth is irrelevant, so each is a single
-collective (RCCL `all_gather_into_tensor`, backend "nccl" on ROCm).  The local top-k and the merge
+Both messages are KB-scale: latency-bound, xGMI bandwidth is irrelevant, so the step has exactly two
+collectives (RCCL `all_gather_into_tensor`, backend "nccl" on ROCm).  MTGV_FORCE_COLLECTIVE=1 runs them at
+world size 1 too (a one-GPU box can then exercise the RCCL path: tests/test_gpu_dist.py).  The local top-k and the merge
 are pluggable so the collective logic is exercised on CPU with gloo (tests/test_dist_cpu.py).
 """
 
 from __future__ import annotations
 
+import os
 from typing import Callable, Tuple
 
 import torch
@@ -51,15 +53,17 @@ def sharded_topk(q_local: torch.Tensor, k: int, local_topk: Callable, merge: Cal
     local_topk(q (B,D), k) -> (ids int64 (B,k) GLOBAL ids, scores (B,k)) over this rank's bank shard.
     merge(cand_scores (B, R*k), cand_ids (B, R*k), k) -> (ids, scores).
     Every rank must pass the same B_local."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    force = os.environ.get("MTGV_FORCE_COLLECTIVE") == "1"
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return local_topk(q_local, k)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     b_local = q_local.shape[0]
     q_all = _all_gather_cat(q_local, group).reshape(world * b_local, -1)
     ids, scores = local_topk(q_all, k)
-    ids_all = _all_gather_cat(ids.contiguous(), group)  # (R, B_total, k)
-    sc_all = _all_gather_cat(scores.contiguous(), group)
-    mine = slice(rank * b_local, (rank + 1) * b_local)
-    cand_i = ids_all[:, mine].permute(1, 0, 2).reshape(b_local, world * k)
-    cand_s = sc_all[:, mine].permute(1, 0, 2).reshape(b_local, world * k)
-    return merge(cand_s.contiguous(), cand_i.contiguous(), k)
+    # one message: [..., 0] = id, [..., 1] = the score's float32 bit pattern
+    packed = torch.stack((ids.to(torch.int64), scores.to(torch.float32).contiguous().view(torch.int32).to(torch.int64)), dim=-1)
+    allp = _all_gather_cat(packed.contiguous(), group)  # (R, B_total, k, 2)
+    mine = allp[:, rank * b_local : (rank + 1) * b_local].permute(1, 0, 2, 3).reshape(b_local, world * k, 2)
+    cand_i = mine[..., 0].contiguous()
+    cand_s = mine[..., 1].to(torch.int32).contiguous().view(torch.float32)
+    return merge(cand_s, cand_i, k)

@@ -68,7 +68,11 @@ class Pipeline:
 
     @staticmethod
     def overlap_enabled() -> bool:
-        return os.environ.get("MTGV_OVERLAP", "on") != "off"
+        """Two-stream overlap is opt-in (MTGV_OVERLAP=on): while the split-precision GEMMs of one stream run, kernels of
+        OTHER libraries that use packed-FP32 VALU instructions on another stream of the same GPU have been seen to lose
+        lanes.  This library is built without those instructions and tests/test_gpu_overlap.py
+        guards its own overlapped path; an application that runs foreign kernels beside it keeps the default."""
+        return os.environ.get("MTGV_OVERLAP", "off") == "on"
 
     def run_many(self, batches, flip_rgb: bool = True):
         """Process a sequence of frame batches with the detect stage of batch i+1 overlapped with the
@@ -76,7 +80,7 @@ class Pipeline:
         tiles to fill 256 CUs on their own; the encoder's GEMMs of the previous batch fill the gaps.
         Results are identical to `run` on each batch (same kernels, same order per stream).
 
-        MTGV_OVERLAP=off keeps everything on the current stream.  (History: with packed-FP32 VALU instructions in
+        Opt-in: without MTGV_OVERLAP=on everything stays on the current stream (see overlap_enabled).  (History: with packed-FP32 VALU instructions in
         the library, kernels sharing a CU with the split-precision GEMM of the other stream sporadically lost a
         packed result in one 16-lane group; the library is built without those instructions - build.py, DESIGN.md
         section 5 - and tests/test_gpu_overlap.py guards the combination.)"""

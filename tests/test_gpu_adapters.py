@@ -1,4 +1,6 @@
 """Drop-in classes (reference names / signatures) on the GPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -94,7 +96,7 @@ def _precision_guard():
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16x3"])
-def test_pipeline_overlap_equals_sequential(mode, _precision_guard):
+def test_pipeline_overlap_equals_sequential(mode, _precision_guard, monkeypatch):
     """run_many (two HIP streams, detect of batch i+1 beside embed of batch i) == run on each batch, bit for bit,
     with either GEMM operand precision"""
     from mtgv import spec
@@ -105,6 +107,8 @@ def test_pipeline_overlap_equals_sequential(mode, _precision_guard):
     from mtgv.matcher import Matcher
     from mtgv.pipeline import Pipeline
 
+    assert not Pipeline.overlap_enabled() or "MTGV_OVERLAP" in os.environ  # opt-in (foreign packed-FP32 kernels)
+    monkeypatch.setenv("MTGV_OVERLAP", "on")
     assert Pipeline.overlap_enabled()
     det_cfg = spec.DetectorConfig()
     enc_cfg = spec.encoder_config("cnvnxt2ae_nano")

@@ -128,3 +128,51 @@ def test_detector_heads_agree_between_modes():
     for a, b in zip(outs["f32"], outs["f16x3"]):
         assert torch.isfinite(b).all()
         assert (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_small_magnitude_weights_before_layernorm(mode):
+    """Layers whose output feeds a LayerNorm directly are scale-free: shrink their weights (stem conv, head pool conv;
+    biases alike) by 1e-3 and the embedding must still be within 1e-4 of the fp64 oracle.  An fp16 split without
+    per-row weight scales has an ABSOLUTE floor of 2^-25 on the lo half and fails this for |w| ~ 1e-5."""
+    from mtgv import native, spec
+    from mtgv.encoder import Encoder
+    from oracle import encoder_ref as R
+
+    native.set_gemm_precision(mode)
+    cfg = spec.encoder_config("cnvnxt2ae_nano", (64, 64), "conv+linear")
+    sd = spec.random_encoder_state(cfg, 5)
+    shrunk = 0
+    for k in list(sd):
+        if k.startswith(("block0.0.", "pool.0.")):  # stem conv and head 1x1 conv: each is followed by a LayerNorm
+            sd[k] = (sd[k] * 1e-3).astype(np.float32)
+            shrunk += 1
+    assert shrunk == 4
+    x = np.random.default_rng(0).random((3, 3, 64, 64), dtype=np.float32)
+    enc = Encoder(cfg, sd, max_batch=3)
+    z = enc.encode(torch.from_numpy(x)).cpu().numpy().astype(np.float64)
+    ref = R.encoder_forward(sd, cfg, torch.from_numpy(x).double(), dtype=torch.float64).numpy()
+    err = np.abs(z - ref).max()
+    print(f"{mode}: shrunk-weights encoder max|z - ref_fp64| = {err:.3e} (|z| max {np.abs(ref).max():.2f})")
+    assert err < TOL
+
+
+def test_linear_large_activations_do_not_overflow():
+    """|a| far beyond the fp16 range (65504): the single-op entry point scales A by a power of two before the split"""
+    from mtgv import native as nv
+
+    nv.set_gemm_precision("f16x3")
+    rng = np.random.default_rng(3)
+    for m, n, k in [(256, 128, 96), (130, 96, 48), (64, 32, 20)]:
+        a = (rng.standard_normal((m, k)) * 3e4).astype(np.float32)
+        a[0, 0], a[m - 1, k - 1] = 1.0e5, -2.5e5
+        w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        out = torch.full((m, n), float("nan"), device="cuda")
+        A, W, B = (torch.from_numpy(t).cuda() for t in (a, w, b))
+        nv.check(nv.lib().mtgv_op_linear(nv.ptr(A), nv.ptr(W), nv.ptr(B), None, nv.ptr(out), m, n, k, 0, nv.stream()))
+        got = out.cpu().double()
+        ref = F.linear(torch.from_numpy(a).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double())
+        assert torch.isfinite(got).all(), (m, n, k)
+        rel = ((got - ref).abs().max() / ref.abs().max()).item()
+        assert rel < 2e-6, (m, n, k, rel)
