@@ -85,8 +85,9 @@ def parse():
     ap.add_argument("--encoder", default="cnvnxt2ae_tiny", help="cnvnxt2ae_tiny | cnvnxt2ae_nano | ...")
     ap.add_argument("--bank", type=int, default=100_000)
     ap.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
-    ap.add_argument("--quads", default="box", choices=["box", "mask"], help="crop the detection boxes (default, SURVEY 8d config 4) or the "
-                    "oriented quads fitted to the detection masks on the GPU")
+    ap.add_argument("--quads", default="mask", choices=["box", "mask"], help="mask (default): crop the oriented quadrilateral fitted to each "
+                    "detection's mask on the GPU, the reference's dataflow (od_export.py:52-111); box: crop the axis-aligned detection "
+                    "boxes (SURVEY 8d config 4 permits them)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"], help="GEMM operand precision (default: library default / MTGV_GEMM_PREC)")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: detect(i) -> embed(i) strictly in sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -222,7 +223,7 @@ def main():
         "config": {
             "workload": f"full pipeline per GPU: {F} frames 640x640x3 u8 -> YOLOv8n-seg(nc=3) detect+NMS+masks -> {K} cards/frame "
             f"-> 192x128 crops -> ConvNeXt-V2 {a.encoder} (z=768) -> cosine top-1 over {a.bank}x768 bank",
-            "crop_quads": "detection boxes" if a.quads == "box" else "oriented quads fitted to the detection masks (mask_quads_kernel)",
+            "crop_quads": "detection boxes" if a.quads == "box" else "4-vertex polygons fitted to the detection masks on the GPU (mask_quads_kernel: hull + approxPolyN + orientation)",
             "frames_per_gpu": F,
             "distinct_frame_batches": NB,
             "cards_per_frame": K,
@@ -321,12 +322,20 @@ def main():
             # bounded CPU sample of the same workload on the host cores: the oracle pipeline
             from oracle import pipeline_ref
 
-            # every host core this process may run on (the scheduler affinity; os.cpu_count() counts the whole host)
+            # Thread count: every host core this process may run on is the upper bound, but PyTorch's CPU kernels
+            # slow down when oversubscribed (256 threads on this pool's hosts: 15x slower than 16), and the box's
+            # CPU share can be a cgroup quota the affinity mask does not show.  Time one frame at a few candidate
+            # counts and keep the fastest; "cores" reports the threads actually used.
             try:
-                nthreads = len(os.sched_getaffinity(0))
+                ncpu = len(os.sched_getaffinity(0))
             except AttributeError:
-                nthreads = os.cpu_count() or 1
-            torch.set_num_threads(nthreads)
+                ncpu = os.cpu_count() or 1
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q != "max":
+                    ncpu = max(1, min(ncpu, int(int(q) / int(per))))
+            except (OSError, ValueError):
+                pass
             cpu_model = "unknown"
             try:
                 for ln in open("/proc/cpuinfo"):
@@ -335,9 +344,18 @@ def main():
                         break
             except OSError:
                 pass
-            cf = min(a.cpu_frames, F)
             bank_cpu = matcher.rows(0, len(matcher))
-            fr = frames[:cf].cpu().numpy()
+            fr = frames[: min(a.cpu_frames, F)].cpu().numpy()
+            tried = {}
+            for nt in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+                torch.set_num_threads(nt)
+                pipeline_ref.run(det_sd, det_cfg, enc_sd, enc_cfg, bank_cpu[:1000], fr[:1], K)  # warm the thread pool
+                t0 = time.perf_counter()
+                pipeline_ref.run(det_sd, det_cfg, enc_sd, enc_cfg, bank_cpu[:1000], fr[:1], K)
+                tried[nt] = round(time.perf_counter() - t0, 3)
+            nthreads = min(tried, key=tried.get)
+            torch.set_num_threads(nthreads)
+            cf = min(a.cpu_frames, F)
             pipeline_ref.run(det_sd, det_cfg, enc_sd, enc_cfg, bank_cpu[:1000], fr[:1], K)  # warm the thread pool
             t0 = time.perf_counter()
             pipeline_ref.run(det_sd, det_cfg, enc_sd, enc_cfg, bank_cpu, fr, K)
@@ -348,6 +366,7 @@ def main():
                 "cores": nthreads,
                 "cpu_model": cpu_model,
                 "host_cpu_count": os.cpu_count(),
+                "seconds_per_frame_by_threads": tried,
                 "kind": "port",
                 "sample": f"{cf} frames x {K} cards of the same synthetic workload through oracle/pipeline_ref.py "
                 f"(PyTorch CPU fp32, {nthreads} threads), {cdt:.1f} s",

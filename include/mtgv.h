@@ -203,6 +203,11 @@ MTGV_API size_t mtgv_nms_workspace_bytes(int32_t n, int32_t na);
  * The quad is the minimum-area rectangle of the mask's convex hull; "up" is mask centroid minus hull centroid. */
 MTGV_API int mtgv_mask_quads(const uint8_t* masks_dev, int32_t n, int32_t h, int32_t w, const float* boxes_dev, float* quads_dev,
                              int32_t* ok_dev, void* stream);
+/* the same from the cropped mask logits (n, mh, mw) of the detector: a pixel of the (mh*scale, mw*scale) mask is foreground
+ * where the bilinear interpolation of the logits is > 0 (what mtgv_mask_binarize writes) - the full-resolution mask is
+ * never materialised.  Identical quads to mtgv_mask_binarize + mtgv_mask_quads. */
+MTGV_API int mtgv_mask_quads_logits(const float* logits_dev, int32_t n, int32_t mh, int32_t mw, int32_t scale,
+                                    const float* boxes_dev, float* quads_dev, int32_t* ok_dev, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Crop: perspective de-warp of card quads.                                   */

@@ -99,35 +99,60 @@ def _largest_contour(mask: np.ndarray) -> np.ndarray:
     return p
 
 
-def _min_area_rect(points: np.ndarray) -> np.ndarray:
-    """4 corners of the minimum-area rectangle around `points` (rotating calipers over the convex hull)."""
-    from scipy.spatial import ConvexHull
+def _convex_hull(points: np.ndarray) -> np.ndarray:
+    """Convex hull (monotone chain) of (P, 2) points, clockwise on the screen (y down), float64."""
+    pts = sorted(set((float(x), float(y)) for x, y in np.asarray(points, np.float64)))
+    if len(pts) <= 2:
+        return np.asarray(pts, np.float64).reshape(-1, 2)
 
-    pts = np.unique(points.astype(np.float64), axis=0)
-    if len(pts) < 3:
-        x1, y1 = pts.min(0)
-        x2, y2 = pts.max(0)
-        return np.asarray([[x1, y1], [x2, y1], [x2, y2], [x1, y2]])
-    try:
-        hull = pts[ConvexHull(pts).vertices]
-    except Exception:
-        x1, y1 = pts.min(0)
-        x2, y2 = pts.max(0)
-        return np.asarray([[x1, y1], [x2, y1], [x2, y2], [x1, y2]])
-    best = None
-    for i in range(len(hull)):
-        e = hull[(i + 1) % len(hull)] - hull[i]
-        n = np.linalg.norm(e)
-        if n == 0:
-            continue
-        ux = e / n
-        uy = np.asarray([-ux[1], ux[0]])
-        a, b = hull @ ux, hull @ uy
-        area = (a.max() - a.min()) * (b.max() - b.min())
-        if best is None or area < best[0]:
-            best = (area, ux, uy, a.min(), a.max(), b.min(), b.max())
-    _, ux, uy, a0, a1, b0, b1 = best
-    return np.asarray([ux * a0 + uy * b0, ux * a1 + uy * b0, ux * a1 + uy * b1, ux * a0 + uy * b1])
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    lower, upper = [], []
+    for p in pts:
+        while len(lower) >= 2 and cross(lower[-2], lower[-1], p) <= 0:
+            lower.pop()
+        lower.append(p)
+    for p in reversed(pts):
+        while len(upper) >= 2 and cross(upper[-2], upper[-1], p) <= 0:
+            upper.pop()
+        upper.append(p)
+    hull = np.asarray(lower[:-1] + upper[:-1], np.float64)
+    x, y = hull[:, 0], hull[:, 1]
+    if (x * np.roll(y, -1) - np.roll(x, -1) * y).sum() < 0:
+        hull = hull[::-1]
+    return hull
+
+
+def _approx_poly_n(hull: np.ndarray, nsides: int = 4):
+    """cv2.approxPolyN(points, nsides) as OpenCV documents it (od_export.py:74): on the convex hull, contract two
+    vertices into one - prolong the two neighbours of an edge to their intersection - wherever that adds the least
+    area, until `nsides` vertices remain.  Every vertex lies on the contour or outside it.  None when the hull has
+    fewer vertices or nothing can be contracted."""
+    v = [tuple(p) for p in np.asarray(hull, np.float64)]
+    if len(v) < nsides:
+        return None
+
+    def added(a, b, c, d):
+        rx, ry, qx, qy, ex, ey = b[0] - a[0], b[1] - a[1], c[0] - d[0], c[1] - d[1], c[0] - b[0], c[1] - b[1]
+        den = rx * qy - ry * qx
+        if den == 0.0:
+            return np.inf, None
+        t, u = (ex * qy - ey * qx) / den, (ex * ry - ey * rx) / den
+        if not (t > 0.0 and u > 0.0):
+            return np.inf, None
+        p = (b[0] + t * rx, b[1] + t * ry)
+        return 0.5 * abs((b[0] - p[0]) * (c[1] - p[1]) - (b[1] - p[1]) * (c[0] - p[0])), p
+
+    while len(v) > nsides:
+        n = len(v)
+        cand = [added(v[i - 1], v[i], v[(i + 1) % n], v[(i + 2) % n]) for i in range(n)]
+        i = int(np.argmin([c[0] for c in cand]))
+        if not np.isfinite(cand[i][0]):
+            return None
+        v[i] = cand[i][1]
+        del v[(i + 1) % n]
+    return np.asarray(v, np.float64)
 
 
 def _poly_centroid(p: np.ndarray) -> np.ndarray:
@@ -177,40 +202,44 @@ class InstanceSeg:
         return self._dir_vec
 
     def _orient(self, mode="u_shape") -> None:
-        """od_export.py:52-93 closes the U-shaped mask with shapely buffer(+/-), takes 4 corners with
-        cv2.approxPolyN and rolls them so that corner 0 is the card's top-left.  shapely / cv2 are absent;
-        this is the build's own statement of the same steps (convex hull as the closed shape, minimum-area
-        rectangle as the quad, centroid difference as the top->bottom direction): SURVEY.md section 8f rank 1."""
+        """od_export.py:52-93: the U-shaped mask is closed (shapely buffer(+d).buffer(-d)); v = centroid(orig) -
+        centroid(closed) points at the card's top; cv2.approxPolyN(points, 4) gives a general 4-vertex polygon; the
+        ray from its centroid along v picks the edge that becomes edge (0, 1); corners are truncated to int.
+        shapely / cv2 are absent: the closed shape is the convex hull (the reference's own fallback, :63-64 - only the
+        direction of v is used) and approxPolyN is restated from OpenCV's documentation (_approx_poly_n).  The GPU
+        path (mtgv.crop.mask_quads / quads.hip) runs the same steps on the detection masks."""
         if self._xyxyxyxy is not None:
             return
         assert mode == "u_shape", "Only u_shape dataset mode is supported"
         pts = np.asarray(self.points, np.float64)
-        box = _min_area_rect(pts)
-        from scipy.spatial import ConvexHull
-
-        try:
-            hull = pts[ConvexHull(pts).vertices]
-        except Exception:
-            hull = box
+        hull = _convex_hull(pts)
+        box = _approx_poly_n(hull, 4) if len(hull) >= 4 else None
+        if box is None:
+            x1, y1 = pts.min(0)
+            x2, y2 = pts.max(0)
+            box = np.asarray([[x1, y1], [x2, y1], [x2, y2], [x1, y2]], np.float64)
         # orig centroid - closed centroid (od_export.py:69-71): the card's bottom is missing from the mask,
         # so this vector points at the card's top edge
-        v = _poly_centroid(pts) - _poly_centroid(hull)
+        v = _poly_centroid(pts) - (_poly_centroid(hull) if len(hull) >= 3 else pts.mean(0))
         nv = np.linalg.norm(v)
         v = v / nv if nv > 0 else np.asarray([0.0, -1.0])
-        # the edge the ray centre + t*v crosses becomes edge (0,1) = top of the de-warped card (od_export.py:77-88)
-        c = box.mean(0)
+        # od_export.py:76-88: first edge i in 1..3 that the ray centroid -> centroid + 1e7 v touches; else edge 0
+        c = _poly_centroid(box)
+        e = c + v * 10000000.0
+
+        def touch(a, b, p, q):
+            d1 = (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])
+            d2 = (b[0] - a[0]) * (q[1] - a[1]) - (b[1] - a[1]) * (q[0] - a[0])
+            d3 = (q[0] - p[0]) * (a[1] - p[1]) - (q[1] - p[1]) * (a[0] - p[0])
+            d4 = (q[0] - p[0]) * (b[1] - p[1]) - (q[1] - p[1]) * (b[0] - p[0])
+            return d1 * d2 <= 0.0 and d3 * d4 <= 0.0
+
         idx = 0
-        best = -np.inf
-        for i in range(4):
-            mid = (box[i] + box[(i + 1) % 4]) / 2 - c
-            d = float(mid @ v)
-            if d > best:
-                best, idx = d, i
+        for i in range(1, 4):
+            if touch(c, e, box[i], box[(i + 1) % 4]):
+                idx = i
+                break
         box = np.roll(box, -idx, axis=0)
-        # corners must run tl, tr, br, bl (clockwise in image coordinates, y down)
-        e0, e1 = box[1] - box[0], box[2] - box[1]
-        if e0[0] * e1[1] - e0[1] * e1[0] < 0:
-            box = np.asarray([box[1], box[0], box[3], box[2]])
         self._xyxyxyxy = box.astype(int)
         self._points_closed = hull.astype(int)
         self._dir_vec = v

@@ -44,8 +44,9 @@ def boxes_to_quads(boxes_xyxy: torch.Tensor) -> torch.Tensor:
 def mask_quads(masks_u8: torch.Tensor, boxes_xyxy: torch.Tensor = None):
     """masks (n, H, W) uint8 on the GPU (non-zero = card) -> (quads (n, 4, 2) float32, ok (n,) int32).
 
-    The quad is the minimum-area rectangle around the mask with corner 0 at the card's top-left - the GPU form of
-    `InstanceSeg._orient` (mtgvision/od_export.py:52-93).  Rows with an empty mask get `boxes_xyxy` (or zeros) and
+    The quad is the 4-vertex polygon cv2.approxPolyN would fit to the mask's hull, rolled so that corner 0 is the
+    card's top-left, corners truncated to integers - the GPU form of `InstanceSeg._orient`
+    (mtgvision/od_export.py:52-93).  Rows with an empty mask get `boxes_xyxy` (or zeros) and
     ok = 0."""
     native.require_gpu()
     assert masks_u8.is_cuda and masks_u8.dtype == torch.uint8 and masks_u8.ndim == 3, f"{tuple(masks_u8.shape)} {masks_u8.dtype}"
@@ -60,4 +61,23 @@ def mask_quads(masks_u8: torch.Tensor, boxes_xyxy: torch.Tensor = None):
     with torch.cuda.device(masks_u8.device):
         native.check(native.lib().mtgv_mask_quads(native.ptr(masks_u8.contiguous()), n, h, w, native.ptr(boxes_xyxy), native.ptr(quads),
                                                   native.ptr(ok), native.stream()))
+    return quads, ok
+
+
+def mask_quads_from_logits(mask_logits: torch.Tensor, boxes_xyxy: torch.Tensor = None, scale: int = 4):
+    """(n, mh, mw) cropped mask logits -> (quads, ok) of the (mh*scale, mw*scale) masks `binarize_masks` would produce,
+    without materialising them (one kernel: interpolate, threshold, row extents, hull, approxPolyN, orientation)."""
+    native.require_gpu()
+    assert mask_logits.is_cuda and mask_logits.dtype == torch.float32 and mask_logits.ndim == 3
+    n, mh, mw = mask_logits.shape
+    quads = torch.zeros((n, 4, 2), dtype=torch.float32, device=mask_logits.device)
+    ok = torch.zeros((n,), dtype=torch.int32, device=mask_logits.device)
+    if n == 0:
+        return quads, ok
+    if boxes_xyxy is not None:
+        boxes_xyxy = boxes_xyxy.to(mask_logits.device, torch.float32).contiguous()
+        assert tuple(boxes_xyxy.shape) == (n, 4), f"{tuple(boxes_xyxy.shape)}"
+    with torch.cuda.device(mask_logits.device):
+        native.check(native.lib().mtgv_mask_quads_logits(native.ptr(mask_logits.contiguous()), n, mh, mw, scale, native.ptr(boxes_xyxy),
+                                                         native.ptr(quads), native.ptr(ok), native.stream()))
     return quads, ok

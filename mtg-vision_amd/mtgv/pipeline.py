@@ -12,8 +12,8 @@ from typing import Callable, Optional
 
 import torch
 
-from .crop import boxes_to_quads, mask_quads, warp_quads
-from .detector import Detector, binarize_masks
+from .crop import boxes_to_quads, mask_quads_from_logits, warp_quads
+from .detector import Detector
 from .encoder import Encoder
 from .matcher import Matcher
 
@@ -47,9 +47,9 @@ class Pipeline:
         boxes = torch.where(have[..., None], det["boxes"][:, :K], self._pad[None].expand(F, K, 4))
         quads = boxes_to_quads(boxes.reshape(F * K, 4))
         if self.quad_source == "mask":
-            # masks of the K best detections (logits are zero outside a detection's box), at frame resolution
-            masks = binarize_masks(det["mask_logits"][:, :K].reshape(F * K, *det["mask_logits"].shape[-2:]))
-            mq, ok = mask_quads(masks, boxes.reshape(F * K, 4))
+            # masks of the K best detections (logits are zero outside a detection's box): interpolated to frame
+            # resolution, thresholded and fitted inside one kernel
+            mq, ok = mask_quads_from_logits(det["mask_logits"][:, :K].reshape(F * K, *det["mask_logits"].shape[-2:]), boxes.reshape(F * K, 4))
             use = (ok.view(F, K) > 0) & have  # no detection / empty mask: keep the box (or pad) quad
             quads = torch.where(use.reshape(F * K, 1, 1), mq, quads)
         frame_idx = torch.arange(F, device=frames_u8.device, dtype=torch.int32).repeat_interleave(K)

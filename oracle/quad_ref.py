@@ -1,17 +1,29 @@
 """CPU oracle of the mask -> oriented card quad step (TEST INFRASTRUCTURE ONLY - never imported by the product).
 
-Restates what `InstanceSeg._orient` does with a detection mask (mtgvision/od_export.py:52-93): close the U-shaped mask,
-take four corners, and roll them so that corner 0 is the card's top-left (the missing bottom of the "U" tells which
-way is up).  The reference leans on third-party geometry (ultralytics `masks.xy` = cv2.findContours, shapely
-buffer(+/-), cv2.approxPolyN - `pyproject.toml:29-42`), none of which is importable here and none of which the
-reference tests: PARITY UNPINNED.  This file states the build's own algorithm, the one `mask_quads_kernel`
-(mtg-vision_amd/csrc/quads.hip) implements, operation for operation so that the GPU result can be compared bit for bit:
+Restates what `InstanceSeg._orient` does with a detection mask (mtgvision/od_export.py:52-93):
+
+  * `closed_poly = orig_poly.buffer(d).buffer(-d)` closes the U-shaped mask (the card's bottom is missing from it);
+    `v = centroid(orig) - centroid(closed)` then points at the card's top (:58-71);
+  * `cv2.approxPolyN(points, 4)` reduces the contour to a general 4-vertex polygon (:74) - NOT a rectangle: a card seen
+    at an angle is a trapezoid, and `extract_dewarped` (:95-111) exists to undo exactly that;
+  * the ray from the quad's centroid along v picks the edge that becomes edge (0, 1), the top of the crop (:76-88);
+  * the corners are truncated to integers (`astype(int)`, :90).
+
+The reference leans on third-party geometry (ultralytics `masks.xy` = cv2.findContours, shapely, cv2.approxPolyN -
+`pyproject.toml:29-42`), none of which is importable here and none of which the reference tests: PARITY UNPINNED.
+This file states the algorithm `mask_quads_kernel` (mtg-vision_amd/csrc/quads.hip) implements, operation for operation,
+so that the GPU result can be compared bit for bit:
 
   1. per mask row: leftmost / rightmost foreground pixel, pixel count, sum of x        (integers)
-  2. convex hull of those extreme pixels, monotone chain ordered by (y, x)             (integer cross products)
-  3. minimum-area rectangle: for every hull edge, extent of the hull along / across it (float64, first minimum wins)
-  4. direction "up" = centroid of the mask pixels - area centroid of the hull          (float64)
-  5. the rectangle edge that lies furthest along "up" becomes edge (0, 1); corners run clockwise (y down)
+  2. convex hull of those extreme pixels (= hull of the mask), monotone chain           (integer cross products)
+  3. approxPolyN as OpenCV documents it ("greedy contraction of two vertices into one so that the area changes
+     minimally; straight lines through the edges are drawn and the areas of the resulting triangles are considered;
+     every vertex lies on the contour or outside it"): while more than 4 vertices remain, remove the hull edge whose
+     two neighbouring edges, prolonged to their intersection, add the smallest triangle (first minimum wins)
+  4. v = centroid of the mask pixels - area centroid of the closed shape.  The closed shape here is the convex hull
+     (what the reference itself falls back to when the buffered polygon falls apart, :63-64); only the direction of
+     v enters the result
+  5. ray test of :76-88, roll, truncation toward zero
 
 Sums run in plain Python loops in the same order as the kernel's sequential sections, so no pairwise-summation or
 FMA difference can appear.
@@ -61,38 +73,6 @@ def hull_of_extents(ys, xmin, xmax):
     return lower[:-1] + upper[:-1]
 
 
-def min_area_rect(hull):
-    """((4, 2) float64 corners, edge index) of the smallest rectangle with a side on a hull edge; first minimum wins."""
-    h = len(hull)
-    best_area, best = math.inf, None
-    for i in range(h):
-        ex = float(hull[(i + 1) % h][0] - hull[i][0])
-        ey = float(hull[(i + 1) % h][1] - hull[i][1])
-        n = math.sqrt(ex * ex + ey * ey)
-        if n == 0.0:
-            continue
-        ux, uy = ex / n, ey / n
-        a0 = b0 = math.inf
-        a1 = b1 = -math.inf
-        for k in range(h):
-            px, py = float(hull[k][0]), float(hull[k][1])
-            a = px * ux + py * uy
-            b = py * ux - px * uy  # along (-uy, ux)
-            a0, a1 = min(a0, a), max(a1, a)
-            b0, b1 = min(b0, b), max(b1, b)
-        area = (a1 - a0) * (b1 - b0)
-        if area < best_area:
-            best_area, best = area, (ux, uy, a0, a1, b0, b1, i)
-    if best is None:
-        return None, -1
-    ux, uy, a0, a1, b0, b1, i = best
-    vx, vy = -uy, ux
-    corners = np.asarray(
-        [[ux * a0 + vx * b0, uy * a0 + vy * b0], [ux * a1 + vx * b0, uy * a1 + vy * b0], [ux * a1 + vx * b1, uy * a1 + vy * b1],
-         [ux * a0 + vx * b1, uy * a0 + vy * b1]], np.float64)
-    return corners, i
-
-
 def hull_centroid(hull):
     """Area centroid (shoelace, sequential float64); vertex mean for degenerate hulls."""
     h = len(hull)
@@ -113,8 +93,80 @@ def hull_centroid(hull):
     return cx / (3.0 * a2), cy / (3.0 * a2)
 
 
+def _contract_area(ax, ay, bx, by, cx, cy, dx, dy):
+    """Removing edge b->c: prolong a->b and d->c to their intersection P.  Returns (added area, Px, Py); inf when the
+    neighbours do not converge beyond the edge."""
+    rx, ry = bx - ax, by - ay
+    qx, qy = cx - dx, cy - dy
+    ex, ey = cx - bx, cy - by
+    den = rx * qy - ry * qx
+    if den == 0.0:
+        return math.inf, 0.0, 0.0
+    t = (ex * qy - ey * qx) / den
+    s = (ex * ry - ey * rx) / den
+    if not (t > 0.0 and s > 0.0):
+        return math.inf, 0.0, 0.0
+    px, py = bx + t * rx, by + t * ry
+    ux, uy = bx - px, by - py
+    wx, wy = cx - px, cy - py
+    return 0.5 * abs(ux * wy - uy * wx), px, py
+
+
+def approx_poly_n(hull, nsides=4):
+    """Greedy edge contraction of a convex polygon (list of (x, y), any numeric type) down to `nsides` vertices.
+    Returns a list of (x, y) floats in the input's orientation, starting at the lowest surviving slot."""
+    h = len(hull)
+    vx = [float(p[0]) for p in hull]
+    vy = [float(p[1]) for p in hull]
+    nxt = [(i + 1) % h for i in range(h)]
+    prv = [(i - 1) % h for i in range(h)]
+    alive = [True] * h
+
+    def area_of(i):
+        a, c = prv[i], nxt[i]
+        d = nxt[c]
+        return _contract_area(vx[a], vy[a], vx[i], vy[i], vx[c], vy[c], vx[d], vy[d])
+
+    ar = [area_of(i)[0] for i in range(h)]
+    cnt = h
+    while cnt > nsides:
+        best, bi = math.inf, -1
+        for i in range(h):
+            if alive[i] and ar[i] < best:
+                best, bi = ar[i], i
+        if bi < 0:
+            break  # nothing can be contracted (parallel neighbours everywhere)
+        _, px, py = area_of(bi)
+        c = nxt[bi]
+        vx[bi], vy[bi] = px, py
+        alive[c] = False
+        nxt[bi] = nxt[c]
+        prv[nxt[c]] = bi
+        cnt -= 1
+        for j in (prv[prv[bi]], prv[bi], bi, nxt[bi]):
+            ar[j] = area_of(j)[0]
+    out = []
+    i0 = next(i for i in range(h) if alive[i])
+    i = i0
+    while True:
+        out.append((vx[i], vy[i]))
+        i = nxt[i]
+        if i == i0:
+            break
+    return out
+
+
+def _segments_touch(ax, ay, bx, by, cx, cy, dx, dy):
+    """closed segments AB and CD intersect (orientation products; what shapely's intersects() decides here)"""
+    d1 = (bx - ax) * (cy - ay) - (by - ay) * (cx - ax)
+    d2 = (bx - ax) * (dy - ay) - (by - ay) * (dx - ax)
+    d3 = (dx - cx) * (ay - cy) - (dy - cy) * (ax - cx)
+    d4 = (dx - cx) * (by - cy) - (dy - cy) * (bx - cx)
+    return d1 * d2 <= 0.0 and d3 * d4 <= 0.0
+
+
 def mask_quad(mask: np.ndarray, box=None):
-    """(quad (4, 2) float32 tl/tr/br/bl, ok).  Empty mask: ok = 0 and the quad is the box (or zeros without a box)."""
+    """(quad (4, 2) float32 tl/tr/br/bl with integer values, ok).  Empty mask: ok = 0 and the quad is the box."""
     ys, xmin, xmax, cnt, sumx = row_extents(mask)
     n = int(cnt.sum())
     if n == 0:
@@ -123,11 +175,18 @@ def mask_quad(mask: np.ndarray, box=None):
         x1, y1, x2, y2 = [np.float32(v) for v in box]
         return np.asarray([[x1, y1], [x2, y1], [x2, y2], [x1, y2]], np.float32), 0
     hull = hull_of_extents(ys, xmin, xmax)
-    rect, _ = min_area_rect(hull) if len(hull) >= 3 else (None, -1)
-    if rect is None:  # a point or a straight run of pixels: its bounding box
+    if len(hull) >= 3:
+        # clockwise on the screen (y down): positive shoelace sum
+        a2 = 0
+        for i in range(len(hull)):
+            a2 += hull[i][0] * hull[(i + 1) % len(hull)][1] - hull[(i + 1) % len(hull)][0] * hull[i][1]
+        if a2 < 0:
+            hull = [hull[0]] + hull[:0:-1]
+    quad = approx_poly_n(hull, 4) if len(hull) >= 4 else None
+    if quad is None or len(quad) != 4:  # fewer than 4 hull vertices (point, line, triangle): the bounding box
         x1, x2 = float(xmin.min()), float(xmax.max())
         y1, y2 = float(ys.min()), float(ys.max())
-        rect = np.asarray([[x1, y1], [x2, y1], [x2, y2], [x1, y2]], np.float64)
+        quad = [(x1, y1), (x2, y1), (x2, y2), (x1, y2)]
     mcx = float(int(sumx.sum())) / float(n)
     mcy = float(int((ys * cnt).sum())) / float(n)
     hcx, hcy = hull_centroid(hull) if len(hull) >= 3 else (mcx, mcy)
@@ -137,21 +196,16 @@ def mask_quad(mask: np.ndarray, box=None):
         vx, vy = vx / nv, vy / nv
     else:
         vx, vy = 0.0, -1.0
-    ccx = (rect[0][0] + rect[1][0] + rect[2][0] + rect[3][0]) / 4.0
-    ccy = (rect[0][1] + rect[1][1] + rect[2][1] + rect[3][1]) / 4.0
-    idx, best = 0, -math.inf
-    for i in range(4):
-        mx = (rect[i][0] + rect[(i + 1) % 4][0]) / 2.0 - ccx
-        my = (rect[i][1] + rect[(i + 1) % 4][1]) / 2.0 - ccy
-        d = mx * vx + my * vy
-        if d > best:
-            best, idx = d, i
-    q = [rect[(idx + i) % 4] for i in range(4)]
-    e0x, e0y = q[1][0] - q[0][0], q[1][1] - q[0][1]
-    e1x, e1y = q[2][0] - q[1][0], q[2][1] - q[1][1]
-    if e0x * e1y - e0y * e1x < 0.0:
-        q = [q[1], q[0], q[3], q[2]]
-    return np.asarray(q, np.float64).astype(np.float32), 1
+    qcx, qcy = hull_centroid(quad)
+    ex, ey = qcx + vx * 10000000.0, qcy + vy * 10000000.0
+    idx = 0
+    for i in range(1, 4):
+        c, d = quad[i], quad[(i + 1) % 4]
+        if _segments_touch(qcx, qcy, ex, ey, c[0], c[1], d[0], d[1]):
+            idx = i
+            break
+    q = [quad[(idx + i) % 4] for i in range(4)]
+    return np.trunc(np.asarray(q, np.float64)).astype(np.float32), 1
 
 
 def mask_quads(masks: np.ndarray, boxes=None):

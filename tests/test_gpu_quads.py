@@ -50,6 +50,54 @@ def test_quads_bit_exact(h, w, n):
     assert ok.sum() >= n // 2
 
 
+def test_perspective_card_on_gpu():
+    """the GPU quad of a card seen at an angle is the generating quadrilateral (<= 1.5 px), not a rectangle"""
+    from test_oracle_quads_cpu import _poly_mask
+
+    quads = np.asarray([[[100, 80], [300, 110], [280, 420], [60, 380]], [[330, 70], [380, 300], [120, 360], [40, 150]],
+                        [[250, 400], [60, 330], [110, 90], [300, 60]]], np.float64)
+    masks = []
+    for quad in quads:
+        m = _poly_mask(480, 420, quad)
+        bc = (quad[2] + quad[3]) / 2
+        inward = quad[:2].mean(0) - bc
+        inward /= np.linalg.norm(inward)
+        along = (quad[2] - quad[3]) / np.linalg.norm(quad[2] - quad[3])
+        yy, xx = np.mgrid[0:480, 0:420].astype(np.float64)
+        du = (xx - bc[0]) * along[0] + (yy - bc[1]) * along[1]
+        dv = (xx - bc[0]) * inward[0] + (yy - bc[1]) * inward[1]
+        masks.append(m & ~((np.abs(du) < 0.3 * np.linalg.norm(quad[2] - quad[3])) & (dv < 60)))
+    q, ok = _gpu(np.stack(masks))
+    assert (ok == 1).all()
+    assert np.abs(q - quads).max() <= 1.5, q
+
+
+def test_quads_from_logits_equal_binarize_then_quads():
+    """the fused kernel (interpolate + threshold + fit, no full-resolution mask) == mtgv_mask_binarize -> mtgv_mask_quads"""
+    from mtgv.crop import mask_quads, mask_quads_from_logits
+    from mtgv.detector import binarize_masks
+
+    rng = np.random.default_rng(12)
+    n, mh, mw = 24, 160, 160
+    lg = np.zeros((n, mh, mw), np.float32)
+    yy, xx = np.mgrid[0:mh, 0:mw]
+    for i in range(n):
+        if i % 6 == 5:
+            continue  # empty mask
+        f = rng.standard_normal((mh // 8 + 1, mw // 8 + 1)).astype(np.float32)
+        field = np.kron(f, np.ones((8, 8), np.float32))[:mh, :mw] + 0.3 * rng.standard_normal((mh, mw)).astype(np.float32)
+        y1, x1 = rng.integers(0, mh // 2), rng.integers(0, mw // 2)
+        y2, x2 = y1 + rng.integers(8, mh // 2), x1 + rng.integers(8, mw // 2)
+        box = (yy >= y1) & (yy < y2) & (xx >= x1) & (xx < x2)
+        lg[i] = np.where(box, field + 0.5, 0.0)  # zero outside the box, as crop_mask leaves the logits
+    L = torch.from_numpy(lg).cuda()
+    boxes = torch.from_numpy(rng.uniform(0, 600, (n, 4)).astype(np.float32)).cuda()
+    q1, ok1 = mask_quads(binarize_masks(L), boxes)
+    q2, ok2 = mask_quads_from_logits(L, boxes)
+    assert torch.equal(ok1, ok2) and torch.equal(q1, q2)
+    assert int(ok1.sum()) >= n // 2 and int((ok1 == 0).sum()) >= 3
+
+
 def test_degenerate_masks_and_errors():
     from mtgv import native
     from oracle import quad_ref as Q

@@ -28,6 +28,45 @@ def test_u_shape_gives_oriented_rectangle(ang):
     assert np.abs(q - want).max() < 2.0, f"{q} vs {want}"  # corner 0 = top-left of the card, clockwise
 
 
+def _poly_mask(h, w, poly):
+    """pixels whose centre lies inside the convex polygon `poly` ((P, 2) x, y, clockwise on the screen)"""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    m = np.ones((h, w), bool)
+    for i in range(len(poly)):
+        a, b = poly[i], poly[(i + 1) % len(poly)]
+        m &= (b[0] - a[0]) * (yy - a[1]) - (b[1] - a[1]) * (xx - a[0]) >= 0
+    return m
+
+
+@pytest.mark.parametrize("quad", [
+    [[100, 80], [300, 110], [280, 420], [60, 380]],      # upright, seen from the right
+    [[330, 70], [380, 300], [120, 360], [40, 150]],      # rolled ~100 degrees, strong keystone
+    [[250, 400], [60, 330], [110, 90], [300, 60]],       # upside down
+])
+def test_perspective_card_recovers_generating_quad(quad):
+    """A card seen at an angle is a general quadrilateral: the recovered quad must be the generating one (<= 1.5 px),
+    corner 0 = the card's top-left.  A minimum-area RECTANGLE cannot pass this (it differs by tens of pixels)."""
+    quad = np.asarray(quad, np.float64)
+    m = _poly_mask(480, 420, quad)
+    # bite the middle of the bottom edge (corners 2 -> 3) out: the U shape of the training masks
+    bc = (quad[2] + quad[3]) / 2
+    inward = quad[:2].mean(0) - bc
+    inward /= np.linalg.norm(inward)
+    along = (quad[2] - quad[3]) / np.linalg.norm(quad[2] - quad[3])
+    yy, xx = np.mgrid[0:480, 0:420].astype(np.float64)
+    du = (xx - bc[0]) * along[0] + (yy - bc[1]) * along[1]
+    dv = (xx - bc[0]) * inward[0] + (yy - bc[1]) * inward[1]
+    m &= ~((np.abs(du) < 0.3 * np.linalg.norm(quad[2] - quad[3])) & (dv < 60))
+    q, ok = Q.mask_quad(m)
+    assert ok == 1
+    assert np.abs(q - quad).max() <= 1.5, f"{q} vs {quad}"
+    # the host statement on the traced contour agrees
+    from mtgv.adapters import InstanceSeg, _largest_contour
+
+    host = np.asarray(InstanceSeg(points=_largest_contour(m), label=0, conf=1.0).xyxyxyxy, np.float64)
+    assert np.abs(host - quad).max() <= 1.5, f"{host} vs {quad}"
+
+
 def test_degenerate_masks():
     m = np.zeros((32, 48), bool)
     q, ok = Q.mask_quad(m, box=[1, 2, 30, 20])
