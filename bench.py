@@ -83,6 +83,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--cards", type=int, default=8, help="cards per frame (K)")
     ap.add_argument("--encoder", default="cnvnxt2ae_tiny", help="cnvnxt2ae_tiny | cnvnxt2ae_nano | ...")
+    ap.add_argument("--detector", default="yolov8n-seg", choices=["yolov8n-seg", "yolo11n-seg"],
+                    help="yolov8n-seg (BASELINE.json) or yolo11n-seg (the family the reference trains by default, od_train.py:20)")
     ap.add_argument("--bank", type=int, default=100_000)
     ap.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
     ap.add_argument("--quads", default="mask", choices=["box", "mask"], help="mask (default): crop the oriented quadrilateral fitted to each "
@@ -136,7 +138,7 @@ def main():
         native.set_gemm_precision(a.precision)
     precision = native.get_gemm_precision()
     F, K = a.frames, a.cards
-    det_cfg = spec.DetectorConfig()
+    det_cfg = spec.yolo11_config() if a.detector == "yolo11n-seg" else spec.DetectorConfig()
     enc_cfg = spec.encoder_config(a.encoder, (192, 128), "conv+linear")
     det_sd = spec.random_detector_state(det_cfg, 3)
     enc_sd = spec.random_encoder_state(enc_cfg, 1)
@@ -221,7 +223,7 @@ def main():
         "dtype": "f32" if precision == "f32" else "f32 (products as 3 x f16 MFMA on hi/lo-split operands, f32 accumulate)",
         "data": "synthetic",
         "config": {
-            "workload": f"full pipeline per GPU: {F} frames 640x640x3 u8 -> YOLOv8n-seg(nc=3) detect+NMS+masks -> {K} cards/frame "
+            "workload": f"full pipeline per GPU: {F} frames 640x640x3 u8 -> {'YOLO11n-seg' if a.detector == 'yolo11n-seg' else 'YOLOv8n-seg'}(nc=3) detect+NMS+masks -> {K} cards/frame "
             f"-> 192x128 crops -> ConvNeXt-V2 {a.encoder} (z=768) -> cosine top-1 over {a.bank}x768 bank",
             "crop_quads": "detection boxes" if a.quads == "box" else "4-vertex polygons fitted to the detection masks on the GPU (mask_quads_kernel: hull + approxPolyN + orientation)",
             "frames_per_gpu": F,

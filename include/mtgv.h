@@ -157,6 +157,7 @@ typedef struct {
   float conf;        /* 0.25 */
   float iou;         /* 0.7 */
   int32_t max_det;   /* 300 */
+  int32_t arch;      /* 0 or 8: YOLOv8n-seg; 11: YOLO11n-seg (C3k2, C2PSA, depthwise class branch; od_train.py:20) */
 } mtgv_detector_cfg;
 
 MTGV_API int mtgv_detector_create(const mtgv_detector_cfg* cfg, mtgv_detector** out);

@@ -10,6 +10,9 @@
 
 namespace mtgv {
 
+// raw head rows per anchor: [0,64) box logits (4 sides x 16 bins), [64,64+nc) class logits, [68,100) mask coefficients
+static constexpr int RAW_CT = 100, RAW_CLS = 64, RAW_COEF = 68;
+
 struct ConvW {
   float* w = nullptr;  // [cout][k][k][cin] BN-folded
   float* b = nullptr;  // [cout]
@@ -56,6 +59,23 @@ class Detector {
   float* upload(const std::vector<float>& v, int row_k = 0);  // row_k > 0: a GEMM B operand with rows of row_k floats
   void conv(const ConvW& w, const View& in, const View& out, int stride, int act, const View* res, int n, hipStream_t s);
   void c2f(int idx, const View& in, const View& out, int n, hipStream_t s);
+  // YOLO11 modules
+  ConvW fold_dw(const std::string& prefix);                         // depthwise 3x3 Conv+BN -> weight [9][c], bias [c]
+  void dwconv(const ConvW& w, const View& in, const View& out, int act, const float* add, int g_size, int g_stride, int n,
+              hipStream_t s);
+  void bottleneck(const std::string& prefix, const View& x, const View& tmp, const View& out, bool shortcut, int n, hipStream_t s);
+  void c3k2(int idx, const View& in, const View& out, int n, hipStream_t s);
+  void c2psa(int idx, const View& in, const View& out, int n, hipStream_t s);
+  void build_v11();
+  void arena_v11();
+  void forward_v11(const uint8_t* frames, int n, int flip, hipStream_t s);
+  void forward_v8(const uint8_t* frames, int n, int flip, hipStream_t s);
+  void head_tail(int n, int* n_det, float* boxes, float* conf, int* cls, int* keep_idx, float* mask_logits, int mask_rows,
+                 hipStream_t s);
+  void conv0(const uint8_t* frames, int n, int flip, hipStream_t s);
+  void sppf(const std::string& prefix, const View& in, const View& spp, const View& out, int n, hipStream_t s);
+  void proto(const std::string& head, const View& p3, int n, hipStream_t s);
+  bool v11() const { return cfg_.arch == 11; }
   View take(int n, int h, int w, int c);
   View view(const std::string& k) const;
 
@@ -71,6 +91,11 @@ class Detector {
   std::map<std::string, ConvW> cw_;
   struct C2fInfo { int cout, n; bool shortcut; int cin; };
   std::map<int, C2fInfo> c2f_;
+  struct C3k2Info { int cout, n, ch; bool c3k; };
+  std::map<int, C3k2Info> c3k2_;
+  ConvW head_bc_[3];            // v11: box + coefficient first convs merged
+  ConvW cls_dw1_[3], cls_pw1_[3], cls_dw2_[3], cls_pw2_[3];
+  std::string head_ = "model.22";
   ConvW head_first_[3], head_box2_[3], head_cls2_[3], head_coef2_[3], head_box3_[3], head_cls3_[3], head_coef3_[3];
   ConvW proto_up_[4];
 

@@ -24,7 +24,6 @@ static int rep(int n) { return n > 1 ? std::max((int)lround(n * 0.33), 1) : n; }
 // decode: DFL expectation -> ltrb -> xywh * stride; class sigmoid; coefficient copy
 // rawhead rows: [0,64) box logits (4 sides x 16 bins), [64,64+nc) class logits, [68,100) coeffs
 // ---------------------------------------------------------------------------
-static constexpr int RAW_CT = 100, RAW_CLS = 64, RAW_COEF = 68;
 
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ r0, const float* __restrict__ r1,
                                                     const float* __restrict__ r2, float* __restrict__ pred, int n, int nc, int nm,
@@ -269,8 +268,14 @@ Detector::Detector(const mtgv_detector_cfg& cfg) : cfg_(cfg) {
   MTGV_CHECK(cfg.imgsz > 0 && cfg.imgsz % 32 == 0, ERR_INVALID, "detector: imgsz=%d must be a multiple of 32", cfg.imgsz);
   MTGV_CHECK(cfg.max_batch > 0, ERR_INVALID, "detector: max_batch=%d", cfg.max_batch);
   MTGV_CHECK(cfg.max_det > 0 && cfg.max_det <= 1024, ERR_INVALID, "detector: max_det=%d", cfg.max_det);
+  MTGV_CHECK(cfg.arch == 0 || cfg.arch == 8 || cfg.arch == 11, ERR_KEY, "detector: arch=%d (8: YOLOv8n-seg, 11: YOLO11n-seg)", cfg.arch);
   const int S = cfg.imgsz;
   na_ = (S / 8) * (S / 8) + (S / 16) * (S / 16) + (S / 32) * (S / 32);
+  if (v11()) {
+    head_ = "model.23";
+    build_v11();
+    return;
+  }
 
   auto P = [](int i) { return "model." + std::to_string(i); };
   // backbone + neck
@@ -308,7 +313,7 @@ Detector::Detector(const mtgv_detector_cfg& cfg) : cfg_(cfg) {
   const int c3 = std::max(chs[0], std::min(cfg.nc, 100));
   const int c4 = std::max(chs[0] / 4, nm_);
   MTGV_CHECK(c2 == 64 && c3 == 64 && c4 == 32, ERR_INVALID, "detector: unexpected head widths");
-  const std::string H = "model.22";
+  const std::string H = head_;
   for (int l = 0; l < 3; ++l) {
     const std::string ls = std::to_string(l);
     expect_conv_bn(H + ".cv2." + ls + ".0", c2, chs[l], 3);
@@ -438,11 +443,16 @@ void Detector::finalize() {
     if (k.size() > suf.size() && k.compare(k.size() - suf.size(), suf.size(), suf) == 0) {
       const std::string pre = k.substr(0, k.size() - suf.size());
       if (raw_.find(pre + ".bn.weight") == raw_.end()) continue;  // dfl.conv has no BatchNorm
+      const Raw& wr = kv.second;
+      if (wr.shape[1] == 1 && wr.shape[0] > 1 && wr.shape[2] == 3) {
+        cw_[pre] = fold_dw(pre);  // depthwise 3x3 (YOLO11 class branch, attention positional encoding)
+        continue;
+      }
       cw_[pre] = fold(pre, pre == "model.0" ? 4 : 0);
     }
   }
-  const std::string H = "model.22";
-  for (int l = 0; l < 3; ++l) {
+  const std::string H = head_;
+  for (int l = 0; l < 3 && !v11(); ++l) {
     const std::string ls = std::to_string(l);
     // the three branches' first 3x3 convs read the same input: one conv with 64+64+32 outputs
     const ConvW &a = cw_.at(H + ".cv2." + ls + ".0"), &b = cw_.at(H + ".cv3." + ls + ".0"), &c = cw_.at(H + ".cv4." + ls + ".0");
@@ -459,6 +469,28 @@ void Detector::finalize() {
     head_box2_[l] = cw_.at(H + ".cv2." + ls + ".1");
     head_cls2_[l] = cw_.at(H + ".cv3." + ls + ".1");
     head_coef2_[l] = cw_.at(H + ".cv4." + ls + ".1");
+    head_box3_[l] = plain(H + ".cv2." + ls + ".2");
+    head_cls3_[l] = plain(H + ".cv3." + ls + ".2");
+    head_coef3_[l] = plain(H + ".cv4." + ls + ".2");
+  }
+  for (int l = 0; l < 3 && v11(); ++l) {
+    const std::string ls = std::to_string(l);
+    // box and coefficient branches start with a 3x3 conv on the same input: one conv with 64+32 outputs
+    const ConvW &a = cw_.at(H + ".cv2." + ls + ".0"), &c = cw_.at(H + ".cv4." + ls + ".0");
+    const size_t per = (size_t)9 * a.cin;
+    std::vector<float> w((size_t)(a.cout + c.cout) * per), bias(a.cout + c.cout);
+    size_t wo = 0, bo = 0;
+    for (const ConvW* q : {&a, &c}) {
+      HIP_OK(hipMemcpy(w.data() + wo, q->w, (size_t)q->cout * per * sizeof(float), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(bias.data() + bo, q->b, (size_t)q->cout * sizeof(float), hipMemcpyDeviceToHost));
+      wo += (size_t)q->cout * per, bo += q->cout;
+    }
+    head_bc_[l].w = upload(w, (int)per), head_bc_[l].b = upload(bias);
+    head_bc_[l].cout = a.cout + c.cout, head_bc_[l].cin = a.cin, head_bc_[l].k = 3;
+    head_box2_[l] = cw_.at(H + ".cv2." + ls + ".1");
+    head_coef2_[l] = cw_.at(H + ".cv4." + ls + ".1");
+    cls_dw1_[l] = cw_.at(H + ".cv3." + ls + ".0.0"), cls_pw1_[l] = cw_.at(H + ".cv3." + ls + ".0.1");
+    cls_dw2_[l] = cw_.at(H + ".cv3." + ls + ".1.0"), cls_pw2_[l] = cw_.at(H + ".cv3." + ls + ".1.1");
     head_box3_[l] = plain(H + ".cv2." + ls + ".2");
     head_cls3_[l] = plain(H + ".cv3." + ls + ".2");
     head_coef3_[l] = plain(H + ".cv4." + ls + ".2");
@@ -484,6 +516,9 @@ void Detector::finalize() {
       }
   }
 
+  if (v11()) {
+    arena_v11();
+  } else {
   // activation arena for max_batch
   const int nb = cfg_.max_batch, S = cfg_.imgsz;
   const int s2 = S / 2, s4 = S / 4, s8 = S / 8, s16 = S / 16, s32 = S / 32;
@@ -540,10 +575,11 @@ void Detector::finalize() {
   v_["protos"] = take(nb, s4, s4, nm_);
   pred_ = take(nb, 1, na_, 4 + cfg_.nc + nm_).p;
   coef_ = take(nb, 1, cfg_.max_det, nm_).p;
+  }
   // rawhead class padding column (index 67) is never written by a conv; keep it defined
   HIP_OK(hipMemset(arena_.p, 0, arena_.n * sizeof(float)));
   if (nms_ws_) (void)hipFree(nms_ws_);
-  nms_ws_bytes_ = nms_workspace_bytes(nb, na_);
+  nms_ws_bytes_ = nms_workspace_bytes(cfg_.max_batch, na_);
   HIP_OK(hipMalloc((void**)&nms_ws_, nms_ws_bytes_));
   finalized_ = true;
 
@@ -594,25 +630,13 @@ void Detector::c2f(int idx, const View& in, const View& out, int n, hipStream_t 
   conv(cw_.at(P + ".cv2"), cat.slice(0, (2 + ci.n) * ch), out, 1, ACT_SILU, nullptr, n, s);
 }
 
-void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float* boxes, float* conf, int* cls, int* keep_idx,
-                       float* mask_logits, int mask_rows, hipStream_t s) {
-  MTGV_CHECK(finalized_, ERR_RUNTIME, "detector: finalize() has not been called");
-  if (!count_flops_) {
-    MTGV_CHECK(n > 0 && n <= cfg_.max_batch, ERR_INVALID, "batch %d outside [1, %d]", n, cfg_.max_batch);
-    MTGV_CHECK(frames && n_det && boxes && conf && cls && keep_idx, ERR_INVALID, "null tensor");
-    MTGV_CHECK(mask_logits == nullptr || (mask_rows > 0 && mask_rows <= cfg_.max_det), ERR_INVALID, "mask_rows=%d", mask_rows);
-  }
+// model.0 (Conv 3 -> 16, k3 s2): on its own kernel straight from the uint8 frame, or (counting mode, f32 debugging
+// switch) through the float copy and the implicit GEMM
+void Detector::conv0(const uint8_t* frames, int n, int flip, hipStream_t s) {
   const int S = cfg_.imgsz;
-  const int c64 = chn(256), c128 = chn(512), c256 = chn(1024);
-  // f16x3 on the LDS-DMA kernel: every intermediate activation is kept in SP8; the frame, the raw head rows and the
-  // prototypes (decode / mask inputs) stay f32
-  fmt_ = (!count_flops_ && gemm_sp_active()) ? 1 : 0;
-  auto V = [&](const char* k) -> View { return view(k); };
-
-  if (fmt_ == 1 || (!count_flops_ && (S / 2) % 4 == 0 && getenv("MTGV_CONV0_GEMM") == nullptr)) {
-    // model.0 on its own kernel, straight from the uint8 frame
+  if (fmt_ == 1 || (!count_flops_ && getenv("MTGV_CONV0_GEMM") == nullptr)) {
     const ConvW& w0 = cw_.at("model.0");
-    const View l0 = V("l0");
+    const View l0 = view("l0");
     const long total = (long)n * (S / 2) * (S / 8);
     MTGV_CHECK((S / 2) % 4 == 0 && w0.cout == 16 && w0.cin == 4 && w0.k == 3, ERR_RUNTIME, "detector: unexpected model.0 geometry");
     if (fmt_ == 1)
@@ -621,23 +645,89 @@ void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float
       hipLaunchKernelGGL((conv0_u8_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, w0.w, w0.b, l0.p, S, flip, total);
     HIP_OK(hipGetLastError());
   } else {
-    if (!count_flops_) u8_to_f32_launch(frames, V("x0").p, (long)n * S * S, 3, 4, 1.0f, 0.0f, flip, s);
-    conv(cw_.at("model.0"), V("x0"), V("l0"), 2, ACT_SILU, nullptr, n, s);
+    if (!count_flops_) u8_to_f32_launch(frames, view("x0").p, (long)n * S * S, 3, 4, 1.0f, 0.0f, flip, s);
+    conv(cw_.at("model.0"), view("x0"), view("l0"), 2, ACT_SILU, nullptr, n, s);
   }
-  conv(cw_.at("model.1"), V("l0"), V("l1"), 2, ACT_SILU, nullptr, n, s);
-  c2f(2, V("l1"), V("l2"), n, s);
-  conv(cw_.at("model.3"), V("l2"), V("l3"), 2, ACT_SILU, nullptr, n, s);
-  const View n4 = V("cat14").slice(c128, c64);      // node 4 output lives in concat 14 = [up(12), 4]
-  c2f(4, V("l3"), n4, n, s);
-  conv(cw_.at("model.5"), n4, V("l5"), 2, ACT_SILU, nullptr, n, s);
-  const View n6 = V("cat11").slice(c256, c128);     // concat 11 = [up(9), 6]
-  c2f(6, V("l5"), n6, n, s);
-  conv(cw_.at("model.7"), n6, V("l7"), 2, ACT_SILU, nullptr, n, s);
-  c2f(8, V("l7"), V("l8"), n, s);
-  // SPPF: cv1, three chained 5x5 max pools, cv2 over the concat
-  const View spp = V("sppcat");
-  const int ch = c256 / 2;
-  conv(cw_.at("model.9.cv1"), V("l8"), spp.slice(0, ch), 1, ACT_SILU, nullptr, n, s);
+}
+
+// Proto: Conv3 -> ConvTranspose2d(k2,s2) as four scattered 1x1 GEMMs -> Conv3 -> Conv1
+void Detector::proto(const std::string& H, const View& p3, int n, hipStream_t s) {
+  conv(cw_.at(H + ".proto.cv1"), p3, view("pr1"), 1, ACT_SILU, nullptr, n, s);
+  {
+    const View in = view("pr1"), out = view("pr2");
+    for (int q = 0; q < 4; ++q) {
+      const ConvW& w = proto_up_[q];
+      GemmArgs g;
+      g.A = in.p, g.W = w.w, g.bias = w.b, g.Out = out.p;
+      g.M = n * in.H * in.W, g.N = w.cout, g.K = w.cin;
+      g.H = in.H, g.Wd = in.W, g.c_total = in.ct, g.c_off = 0, g.Cin = w.cin;
+      g.OH = in.H, g.OW = in.W;
+      g.os = 2, g.oy = q >> 1, g.ox = q & 1, g.OH2 = out.H, g.OW2 = out.W;
+      g.ldo = out.ct;
+      g.a_fmt = in.fmt, g.out_fmt = out.fmt;
+      if (count_flops_)
+        flops_ += 2.0 * g.M * g.N * g.K;
+      else
+        gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+    }
+  }
+  conv(cw_.at(H + ".proto.cv2"), view("pr2"), view("pr3"), 1, ACT_SILU, nullptr, n, s);
+  conv(cw_.at(H + ".proto.cv3"), view("pr3"), view("protos"), 1, ACT_SILU, nullptr, n, s);
+}
+
+// decode -> NMS -> mask logits of the kept detections
+void Detector::head_tail(int n, int* n_det, float* boxes, float* conf, int* cls, int* keep_idx, float* mask_logits, int mask_rows,
+                         hipStream_t s) {
+  const int S = cfg_.imgsz;
+  const long tot = (long)n * na_;
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rawhead_[0], rawhead_[1], rawhead_[2],
+                     pred_, n, cfg_.nc, nm_, S, na_);
+  HIP_OK(hipGetLastError());
+  nms_launch(pred_, n, cfg_.nc, nm_, na_, cfg_.conf, cfg_.iou, cfg_.max_det, 7680.0f, n_det, boxes, conf, cls, keep_idx, coef_,
+             nms_ws_, nms_ws_bytes_, s);
+  if (mask_logits != nullptr) {
+    // masks = coeffs @ protos^T per image, cropped to the box (process_mask / crop_mask)
+    const View pr = view("protos");
+    const int npx = pr.H * pr.W;
+    GemmArgs g = linear_args(coef_, nm_, pr.p, nullptr, mask_logits, npx, mask_rows, npx, nm_, ACT_NONE);
+    g.batch = n;
+    g.strideA = (long)cfg_.max_det * nm_;
+    g.strideW = (long)npx * nm_;
+    g.strideO = (long)mask_rows * npx;
+    g.m_count = n_det;
+    g.crop_boxes = boxes;
+    g.crop_rows = cfg_.max_det;
+    g.crop_scale = (float)pr.W / (float)S;
+    g.crop_w = pr.W;
+    gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+  }
+}
+
+void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float* boxes, float* conf, int* cls, int* keep_idx,
+                       float* mask_logits, int mask_rows, hipStream_t s) {
+  MTGV_CHECK(finalized_, ERR_RUNTIME, "detector: finalize() has not been called");
+  if (!count_flops_) {
+    MTGV_CHECK(n > 0 && n <= cfg_.max_batch, ERR_INVALID, "batch %d outside [1, %d]", n, cfg_.max_batch);
+    MTGV_CHECK(frames && n_det && boxes && conf && cls && keep_idx, ERR_INVALID, "null tensor");
+    MTGV_CHECK(mask_logits == nullptr || (mask_rows > 0 && mask_rows <= cfg_.max_det), ERR_INVALID, "mask_rows=%d", mask_rows);
+  }
+  // f16x3 on the LDS-DMA kernel: every intermediate activation is kept in SP8; the frame, the raw head rows and the
+  // prototypes (decode / mask inputs) stay f32
+  fmt_ = (!count_flops_ && gemm_sp_active()) ? 1 : 0;
+  if (v11()) {
+    forward_v11(frames, n, flip, s);
+  } else {
+    forward_v8(frames, n, flip, s);
+  }
+  if (count_flops_) return;
+  head_tail(n, n_det, boxes, conf, cls, keep_idx, mask_logits, mask_rows, s);
+  last_n_ = n;
+}
+
+// SPPF: cv1, three chained 5x5 max pools, cv2 over the concat
+void Detector::sppf(const std::string& P, const View& in, const View& spp, const View& out, int n, hipStream_t s) {
+  const int ch = spp.ct / 4;
+  conv(cw_.at(P + ".cv1"), in, spp.slice(0, ch), 1, ACT_SILU, nullptr, n, s);
   if (!count_flops_)
     for (int i = 0; i < 3; ++i) {
       if (fmt_ == 1) {
@@ -649,8 +739,25 @@ void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float
         maxpool5_launch(spp.p, spp.ct, i * ch, spp.p, spp.ct, (i + 1) * ch, n, spp.H, spp.W, ch, s);
       }
     }
+  conv(cw_.at(P + ".cv2"), spp, out, 1, ACT_SILU, nullptr, n, s);
+}
+
+void Detector::forward_v8(const uint8_t* frames, int n, int flip, hipStream_t s) {
+  const int c64 = chn(256), c128 = chn(512), c256 = chn(1024);
+  auto V = [&](const char* k) -> View { return view(k); };
+  conv0(frames, n, flip, s);
+  conv(cw_.at("model.1"), V("l0"), V("l1"), 2, ACT_SILU, nullptr, n, s);
+  c2f(2, V("l1"), V("l2"), n, s);
+  conv(cw_.at("model.3"), V("l2"), V("l3"), 2, ACT_SILU, nullptr, n, s);
+  const View n4 = V("cat14").slice(c128, c64);      // node 4 output lives in concat 14 = [up(12), 4]
+  c2f(4, V("l3"), n4, n, s);
+  conv(cw_.at("model.5"), n4, V("l5"), 2, ACT_SILU, nullptr, n, s);
+  const View n6 = V("cat11").slice(c256, c128);     // concat 11 = [up(9), 6]
+  c2f(6, V("l5"), n6, n, s);
+  conv(cw_.at("model.7"), n6, V("l7"), 2, ACT_SILU, nullptr, n, s);
+  c2f(8, V("l7"), V("l8"), n, s);
   const View n9 = V("cat20").slice(c128, c256);     // concat 20 = [19, 9]
-  conv(cw_.at("model.9.cv2"), spp, n9, 1, ACT_SILU, nullptr, n, s);
+  sppf("model.9", V("l8"), V("sppcat"), n9, n, s);
   // top-down
   const View cat11 = V("cat11"), cat14 = V("cat14"), cat17 = V("cat17"), cat20 = V("cat20");
   if (!count_flops_) upsample2x_launch(n9.p, n9.ct, n9.co, cat11.p, cat11.ct, 0, n, n9.H, n9.W, c256, s);
@@ -679,53 +786,7 @@ void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float
     conv(head_cls3_[l], t2.slice(64, 64), rh.slice(RAW_CLS, cfg_.nc), 1, ACT_NONE, nullptr, n, s);
     conv(head_coef3_[l], t2.slice(128, 32), rh.slice(RAW_COEF, nm_), 1, ACT_NONE, nullptr, n, s);
   }
-  // Proto: Conv3 -> ConvTranspose2d(k2,s2) as four scattered 1x1 GEMMs -> Conv3 -> Conv1
-  conv(cw_.at("model.22.proto.cv1"), V("p3"), V("pr1"), 1, ACT_SILU, nullptr, n, s);
-  {
-    const View in = V("pr1"), out = V("pr2");
-    for (int q = 0; q < 4; ++q) {
-      const ConvW& w = proto_up_[q];
-      GemmArgs g;
-      g.A = in.p, g.W = w.w, g.bias = w.b, g.Out = out.p;
-      g.M = n * in.H * in.W, g.N = w.cout, g.K = w.cin;
-      g.H = in.H, g.Wd = in.W, g.c_total = in.ct, g.c_off = 0, g.Cin = w.cin;
-      g.OH = in.H, g.OW = in.W;
-      g.os = 2, g.oy = q >> 1, g.ox = q & 1, g.OH2 = out.H, g.OW2 = out.W;
-      g.ldo = out.ct;
-      g.a_fmt = in.fmt, g.out_fmt = out.fmt;
-      if (count_flops_)
-        flops_ += 2.0 * g.M * g.N * g.K;
-      else
-        gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
-    }
-  }
-  conv(cw_.at("model.22.proto.cv2"), V("pr2"), V("pr3"), 1, ACT_SILU, nullptr, n, s);
-  conv(cw_.at("model.22.proto.cv3"), V("pr3"), V("protos"), 1, ACT_SILU, nullptr, n, s);
-  if (count_flops_) return;
-
-  const long tot = (long)n * na_;
-  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rawhead_[0], rawhead_[1], rawhead_[2],
-                     pred_, n, cfg_.nc, nm_, S, na_);
-  HIP_OK(hipGetLastError());
-  nms_launch(pred_, n, cfg_.nc, nm_, na_, cfg_.conf, cfg_.iou, cfg_.max_det, 7680.0f, n_det, boxes, conf, cls, keep_idx, coef_,
-             nms_ws_, nms_ws_bytes_, s);
-  if (mask_logits != nullptr) {
-    // masks = coeffs @ protos^T per image, cropped to the box (process_mask / crop_mask)
-    const View pr = V("protos");
-    const int npx = pr.H * pr.W;
-    GemmArgs g = linear_args(coef_, nm_, pr.p, nullptr, mask_logits, npx, mask_rows, npx, nm_, ACT_NONE);
-    g.batch = n;
-    g.strideA = (long)cfg_.max_det * nm_;
-    g.strideW = (long)npx * nm_;
-    g.strideO = (long)mask_rows * npx;
-    g.m_count = n_det;
-    g.crop_boxes = boxes;
-    g.crop_rows = cfg_.max_det;
-    g.crop_scale = (float)pr.W / (float)S;
-    g.crop_w = pr.W;
-    gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
-  }
-  last_n_ = n;
+  proto(head_, V("p3"), n, s);
 }
 
 void Detector::raw(int n, float* pred, float* protos, hipStream_t s) {

@@ -67,6 +67,7 @@ class Detector:
         c = native.DetectorCfg()
         c.nc, c.imgsz, c.max_batch = self.cfg.nc, self.cfg.imgsz, self.max_batch
         c.conf, c.iou, c.max_det = self.cfg.conf, self.cfg.iou, self.cfg.max_det
+        c.arch = 11 if self.cfg.arch == "11" else 8
         self._h = native.c_vp(0)
         with torch.cuda.device(self.device):
             native.check(native.lib().mtgv_detector_create(C.byref(c), C.byref(self._h)))

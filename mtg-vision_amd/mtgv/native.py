@@ -43,6 +43,7 @@ class DetectorCfg(C.Structure):
         ("conf", c_f32),
         ("iou", c_f32),
         ("max_det", c_i32),
+        ("arch", c_i32),
     ]
 
 

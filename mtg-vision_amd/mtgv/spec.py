@@ -262,6 +262,8 @@ def strip_checkpoint_prefix(state_dict, prefix: str = "model.encoder."):
 
 @dataclass(frozen=True)
 class DetectorConfig:
+    # "v8": yolov8n-seg (BASELINE.json); "11": yolo11n-seg, what the reference trains by default (od_train.py:20, :55-56)
+    arch: str = "v8"
     nc: int = 3  # od_train.py:46-50
     nm: int = 32  # mask coefficients
     npr: int = 64  # proto channels (256 * width 0.25)
@@ -284,6 +286,10 @@ class DetectorConfig:
 
     def rep(self, n: int) -> int:
         return max(round(n * self.depth), 1) if n > 1 else n
+
+    @property
+    def head_index(self) -> int:
+        return 23 if self.arch == "11" else 22
 
     @property
     def num_anchors(self) -> int:
@@ -324,6 +330,49 @@ def yolov8_seg_graph(cfg: DetectorConfig):
     ]
 
 
+def yolo11_config(**kw) -> DetectorConfig:
+    """yolo11n-seg: scale "n" of ultralytics cfg/models/11/yolo11-seg.yaml = depth 0.50, width 0.25, max_channels 1024"""
+    return DetectorConfig(arch="11", depth=0.50, **kw)
+
+
+# ---- YOLO11n-seg graph (ultralytics cfg/models/11/yolo11-seg.yaml, scale "n") ----------
+# C3k2(cout, n, c3k, e) | C2PSA(cout, n); the rest as above.  [external - recalled from ultralytics 8.3.x]
+def yolo11_seg_graph(cfg: DetectorConfig):
+    c, r = cfg.ch, cfg.rep
+    return [
+        (0, "Conv", (c(64), 3, 2)),
+        (1, "Conv", (c(128), 3, 2)),
+        (2, "C3k2", (c(256), r(2), False, 0.25)),
+        (3, "Conv", (c(256), 3, 2)),
+        (4, "C3k2", (c(512), r(2), False, 0.25)),
+        (5, "Conv", (c(512), 3, 2)),
+        (6, "C3k2", (c(512), r(2), True, 0.5)),
+        (7, "Conv", (c(1024), 3, 2)),
+        (8, "C3k2", (c(1024), r(2), True, 0.5)),
+        (9, "SPPF", (c(1024),)),
+        (10, "C2PSA", (c(1024), r(2))),
+        (11, "Upsample", ()),
+        (12, "Concat", (11, 6)),
+        (13, "C3k2", (c(512), r(2), False, 0.5)),
+        (14, "Upsample", ()),
+        (15, "Concat", (14, 4)),
+        (16, "C3k2", (c(256), r(2), False, 0.5)),
+        (17, "Conv", (c(256), 3, 2)),
+        (18, "Concat", (17, 13)),
+        (19, "C3k2", (c(512), r(2), False, 0.5)),
+        (20, "Conv", (c(512), 3, 2)),
+        (21, "Concat", (20, 10)),
+        (22, "C3k2", (c(1024), r(2), True, 0.5)),
+    ]
+
+
+def detector_graph(cfg: DetectorConfig):
+    """(graph, indices of the P3 / P4 / P5 feature maps the Segment head reads)"""
+    if cfg.arch == "11":
+        return yolo11_seg_graph(cfg), (16, 19, 22)
+    return yolov8_seg_graph(cfg), (15, 18, 21)
+
+
 def _conv_bn_keys(prefix: str, cout: int, cin: int, k: int):
     return OrderedDict(
         [
@@ -336,8 +385,21 @@ def _conv_bn_keys(prefix: str, cout: int, cin: int, k: int):
     )
 
 
+def _c3k_keys(prefix: str, c1: int, c2: int, n: int = 2):
+    """C3k(c1, c2, n, e=0.5, k=3): cv1, cv2 (1x1 c1 -> c_), cv3 (1x1 2c_ -> c2), n Bottlenecks(c_, c_, 3x3, 3x3, e=1)"""
+    c_ = c2 // 2
+    out = OrderedDict()
+    out.update(_conv_bn_keys(f"{prefix}.cv1", c_, c1, 1))
+    out.update(_conv_bn_keys(f"{prefix}.cv2", c_, c1, 1))
+    out.update(_conv_bn_keys(f"{prefix}.cv3", c2, 2 * c_, 1))
+    for j in range(n):
+        out.update(_conv_bn_keys(f"{prefix}.m.{j}.cv1", c_, c_, 3))
+        out.update(_conv_bn_keys(f"{prefix}.m.{j}.cv2", c_, c_, 3))
+    return out
+
+
 def detector_param_shapes(cfg: DetectorConfig) -> "OrderedDict[str, tuple]":
-    """ultralytics state_dict keys of YOLOv8n-seg (``num_batches_tracked`` buffers omitted).
+    """ultralytics state_dict keys of YOLOv8n-seg / YOLO11n-seg (``num_batches_tracked`` buffers omitted).
 
     Third-party layout, recalled from ultralytics 8.3.x (pyproject.toml:32 pins ~=8.3.80); it
     cannot be checked against the package in this environment.
@@ -345,7 +407,8 @@ def detector_param_shapes(cfg: DetectorConfig) -> "OrderedDict[str, tuple]":
     out: "OrderedDict[str, tuple]" = OrderedDict()
     chans = {-1: 3}
     prev = 3
-    for idx, kind, a in yolov8_seg_graph(cfg):
+    graph, feats = detector_graph(cfg)
+    for idx, kind, a in graph:
         p = f"model.{idx}"
         if kind == "Conv":
             cout, k, _ = a
@@ -360,6 +423,35 @@ def detector_param_shapes(cfg: DetectorConfig) -> "OrderedDict[str, tuple]":
                 out.update(_conv_bn_keys(f"{p}.m.{j}.cv1", ch, ch, 3))
                 out.update(_conv_bn_keys(f"{p}.m.{j}.cv2", ch, ch, 3))
             prev = cout
+        elif kind == "C3k2":
+            # C2f skeleton with hidden width int(cout * e); the inner modules are Bottleneck(c, c, e=0.5) or C3k(c, c, 2)
+            cout, n, c3k, e = a
+            ch = int(cout * e)
+            out.update(_conv_bn_keys(f"{p}.cv1", 2 * ch, prev, 1))
+            out.update(_conv_bn_keys(f"{p}.cv2", cout, (2 + n) * ch, 1))
+            for j in range(n):
+                if c3k:
+                    out.update(_c3k_keys(f"{p}.m.{j}", ch, ch, 2))
+                else:
+                    out.update(_conv_bn_keys(f"{p}.m.{j}.cv1", ch // 2, ch, 3))
+                    out.update(_conv_bn_keys(f"{p}.m.{j}.cv2", ch, ch // 2, 3))
+            prev = cout
+        elif kind == "C2PSA":
+            # cv1 (1x1 c1 -> 2c), n PSABlocks on one half (attention with num_heads = c // 64, then a 2-layer FFN), cv2
+            cout, n = a
+            ch = cout // 2
+            out.update(_conv_bn_keys(f"{p}.cv1", 2 * ch, prev, 1))
+            out.update(_conv_bn_keys(f"{p}.cv2", cout, 2 * ch, 1))
+            nh = max(ch // 64, 1)
+            kd = (ch // nh) // 2  # key_dim = head_dim * attn_ratio (0.5)
+            for j in range(n):
+                q = f"{p}.m.{j}"
+                out.update(_conv_bn_keys(f"{q}.attn.qkv", ch + 2 * nh * kd, ch, 1))
+                out.update(_conv_bn_keys(f"{q}.attn.proj", ch, ch, 1))
+                out.update(_conv_bn_keys(f"{q}.attn.pe", ch, 1, 3))  # depthwise
+                out.update(_conv_bn_keys(f"{q}.ffn.0", 2 * ch, ch, 1))
+                out.update(_conv_bn_keys(f"{q}.ffn.1", ch, 2 * ch, 1))
+            prev = cout
         elif kind == "SPPF":
             (cout,) = a
             out.update(_conv_bn_keys(f"{p}.cv1", prev // 2, prev, 1))
@@ -368,17 +460,27 @@ def detector_param_shapes(cfg: DetectorConfig) -> "OrderedDict[str, tuple]":
         elif kind == "Concat":
             prev = sum(chans[s] for s in a)
         chans[idx] = prev
-    ch = [chans[15], chans[18], chans[21]]
-    p = "model.22"
+    ch = [chans[f] for f in feats]
+    p = f"model.{cfg.head_index}"
     c2 = max(16, ch[0] // 4, cfg.reg_max * 4)
     c3 = max(ch[0], min(cfg.nc, 100))
     c4 = max(ch[0] // 4, cfg.nm)
-    for name, cmid, cout in (("cv2", c2, 4 * cfg.reg_max), ("cv3", c3, cfg.nc)):
-        for l, cl in enumerate(ch):
-            out.update(_conv_bn_keys(f"{p}.{name}.{l}.0", cmid, cl, 3))
-            out.update(_conv_bn_keys(f"{p}.{name}.{l}.1", cmid, cmid, 3))
-            out[f"{p}.{name}.{l}.2.weight"] = (cout, cmid, 1, 1)
-            out[f"{p}.{name}.{l}.2.bias"] = (cout,)
+    for l, cl in enumerate(ch):
+        out.update(_conv_bn_keys(f"{p}.cv2.{l}.0", c2, cl, 3))
+        out.update(_conv_bn_keys(f"{p}.cv2.{l}.1", c2, c2, 3))
+        out[f"{p}.cv2.{l}.2.weight"] = (4 * cfg.reg_max, c2, 1, 1)
+        out[f"{p}.cv2.{l}.2.bias"] = (4 * cfg.reg_max,)
+    for l, cl in enumerate(ch):
+        if cfg.arch == "11":  # Detect(legacy=False): Sequential(DWConv(x, x, 3), Conv(x, c3, 1)), Sequential(DWConv(c3, c3, 3), Conv(c3, c3, 1))
+            out.update(_conv_bn_keys(f"{p}.cv3.{l}.0.0", cl, 1, 3))
+            out.update(_conv_bn_keys(f"{p}.cv3.{l}.0.1", c3, cl, 1))
+            out.update(_conv_bn_keys(f"{p}.cv3.{l}.1.0", c3, 1, 3))
+            out.update(_conv_bn_keys(f"{p}.cv3.{l}.1.1", c3, c3, 1))
+        else:
+            out.update(_conv_bn_keys(f"{p}.cv3.{l}.0", c3, cl, 3))
+            out.update(_conv_bn_keys(f"{p}.cv3.{l}.1", c3, c3, 3))
+        out[f"{p}.cv3.{l}.2.weight"] = (cfg.nc, c3, 1, 1)
+        out[f"{p}.cv3.{l}.2.bias"] = (cfg.nc,)
     out[f"{p}.dfl.conv.weight"] = (1, cfg.reg_max, 1, 1)
     out.update(_conv_bn_keys(f"{p}.proto.cv1", cfg.npr, ch[0], 3))
     out[f"{p}.proto.upsample.weight"] = (cfg.npr, cfg.npr, 2, 2)  # ConvTranspose2d: (in, out, kh, kw)

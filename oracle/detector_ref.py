@@ -1,6 +1,7 @@
 """ORACLE (test infrastructure, never shipped or measured as the product).
 
-CPU restatement of the YOLOv8n-seg detector that mtg-vision's `CardSegmenter` delegates to
+CPU restatement of the YOLO-seg detector (YOLOv8n-seg, and YOLO11n-seg with C3k2 / C2PSA / DWConv class branch - the
+architecture od_train.py:20, :55-56 trains by default) that mtg-vision's `CardSegmenter` delegates to
 (mtgvision/od_export.py:141-160: `YOLO(path, task="segment")([rgb_im])[0]`, then
 `results.masks.xy` / `results.boxes.conf`; model family fixed by od_train.py:46-70).
 
@@ -49,20 +50,91 @@ def _sppf(x, p, prefix, eps):
     return _conv(torch.cat(y, 1), p, f"{prefix}.cv2", 1, eps=eps)
 
 
+def _bottleneck(x, p, prefix, shortcut, eps):
+    """Bottleneck(c1, c2, shortcut, k=(3, 3)): cv2(cv1(x)) (+ x when shortcut and c1 == c2)"""
+    t = _conv(_conv(x, p, f"{prefix}.cv1", 3, eps=eps), p, f"{prefix}.cv2", 3, eps=eps)
+    return x + t if shortcut else t
+
+
+def _c3k(x, p, prefix, n, shortcut, eps):
+    """C3k = C3 with kernel 3: cv3(cat(m(cv1(x)), cv2(x))), m = n Bottlenecks(c_, c_, e=1.0)"""
+    a = _conv(x, p, f"{prefix}.cv1", 1, eps=eps)
+    for j in range(n):
+        a = _bottleneck(a, p, f"{prefix}.m.{j}", shortcut, eps)
+    return _conv(torch.cat((a, _conv(x, p, f"{prefix}.cv2", 1, eps=eps)), 1), p, f"{prefix}.cv3", 1, eps=eps)
+
+
+def _c3k2(x, p, prefix, n, c3k, eps):
+    """C3k2(c1, c2, n, c3k, e): the C2f skeleton (shortcut=True) with Bottleneck(c, c, e=0.5) or C3k(c, c, 2) inside.
+    [external: ultralytics 8.3.x nn/modules/block.py]"""
+    y = list(_conv(x, p, f"{prefix}.cv1", 1, eps=eps).chunk(2, 1))
+    for j in range(n):
+        y.append(_c3k(y[-1], p, f"{prefix}.m.{j}", 2, True, eps) if c3k else _bottleneck(y[-1], p, f"{prefix}.m.{j}", True, eps))
+    return _conv(torch.cat(y, 1), p, f"{prefix}.cv2", 1, eps=eps)
+
+
+def _dwconv(x, p, prefix, eps, act=True):
+    """DWConv(c, c, 3): depthwise Conv2d(groups=c, bias=False) + BatchNorm2d (+ SiLU)"""
+    c = x.shape[1]
+    x = F.conv2d(x, p[f"{prefix}.conv.weight"], None, stride=1, padding=1, groups=c)
+    x = F.batch_norm(
+        x, p[f"{prefix}.bn.running_mean"], p[f"{prefix}.bn.running_var"], p[f"{prefix}.bn.weight"], p[f"{prefix}.bn.bias"], False, 0.0, eps
+    )
+    return F.silu(x) if act else x
+
+
+def _attention(x, p, prefix, num_heads, eps):
+    """Attention(dim, num_heads, attn_ratio=0.5): qkv 1x1 (no act) -> per head softmax(q^T k * kd^-0.5) -> v attn^T
+    + depthwise 3x3 positional encoding of v -> proj 1x1 (no act)"""
+    b, c, h, w = x.shape
+    n = h * w
+    hd = c // num_heads
+    kd = hd // 2
+    qkv = _conv(x, p, f"{prefix}.qkv", 1, eps=eps, act=False)
+    q, k, v = qkv.view(b, num_heads, 2 * kd + hd, n).split([kd, kd, hd], dim=2)
+    attn = (q.transpose(-2, -1) @ k) * (kd ** -0.5)
+    attn = attn.softmax(dim=-1)
+    y = (v @ attn.transpose(-2, -1)).view(b, c, h, w) + _dwconv(v.reshape(b, c, h, w), p, f"{prefix}.pe", eps, act=False)
+    return _conv(y, p, f"{prefix}.proj", 1, eps=eps, act=False)
+
+
+def _c2psa(x, p, prefix, n, eps):
+    """C2PSA(c1, c1, n, e=0.5): a, b = cv1(x).split; b through n PSABlocks (x + attn(x); x + ffn(x)); cv2(cat(a, b))"""
+    a, b = _conv(x, p, f"{prefix}.cv1", 1, eps=eps).chunk(2, 1)
+    nh = max(b.shape[1] // 64, 1)
+    for j in range(n):
+        q = f"{prefix}.m.{j}"
+        b = b + _attention(b, p, f"{q}.attn", nh, eps)
+        b = b + _conv(_conv(b, p, f"{q}.ffn.0", 1, eps=eps), p, f"{q}.ffn.1", 1, eps=eps, act=False)
+    return _conv(torch.cat((a, b), 1), p, f"{prefix}.cv2", 1, eps=eps)
+
+
 def _branch(x, p, prefix, eps):
     x = _conv(x, p, f"{prefix}.0", 3, eps=eps)
     x = _conv(x, p, f"{prefix}.1", 3, eps=eps)
     return F.conv2d(x, p[f"{prefix}.2.weight"], p[f"{prefix}.2.bias"])
 
 
+def _branch_dw(x, p, prefix, eps):
+    """YOLO11 class branch (Detect, legacy=False): (DWConv 3x3, Conv 1x1) twice, then Conv2d 1x1"""
+    x = _conv(_dwconv(x, p, f"{prefix}.0.0", eps), p, f"{prefix}.0.1", 1, eps=eps)
+    x = _conv(_dwconv(x, p, f"{prefix}.1.0", eps), p, f"{prefix}.1.1", 1, eps=eps)
+    return F.conv2d(x, p[f"{prefix}.2.weight"], p[f"{prefix}.2.bias"])
+
+
 def backbone_neck(x, p, cfg: spec.DetectorConfig):
     outs = {}
-    for idx, kind, a in spec.yolov8_seg_graph(cfg):
+    graph, feats = spec.detector_graph(cfg)
+    for idx, kind, a in graph:
         pre = f"model.{idx}"
         if kind == "Conv":
             x = _conv(x, p, pre, a[1], a[2], cfg.bn_eps)
         elif kind == "C2f":
             x = _c2f(x, p, pre, a[1], a[2], cfg.bn_eps)
+        elif kind == "C3k2":
+            x = _c3k2(x, p, pre, a[1], a[2], cfg.bn_eps)
+        elif kind == "C2PSA":
+            x = _c2psa(x, p, pre, a[1], cfg.bn_eps)
         elif kind == "SPPF":
             x = _sppf(x, p, pre, cfg.bn_eps)
         elif kind == "Upsample":
@@ -70,7 +142,7 @@ def backbone_neck(x, p, cfg: spec.DetectorConfig):
         elif kind == "Concat":
             x = torch.cat([outs[s] for s in a], 1)
         outs[idx] = x
-    return [outs[15], outs[18], outs[21]]
+    return [outs[f] for f in feats]
 
 
 def make_anchors(cfg: spec.DetectorConfig):
@@ -87,16 +159,17 @@ def make_anchors(cfg: spec.DetectorConfig):
 
 def head(feats, p, cfg: spec.DetectorConfig):
     """Segment head: returns pred (B, 4+nc+nm, A) [xywh px, class sigmoid, coeffs] and protos (B, nm, 160, 160)."""
-    pre = "model.22"
+    pre = f"model.{cfg.head_index}"
     eps = cfg.bn_eps
     b = feats[0].shape[0]
+    cls_branch = _branch_dw if cfg.arch == "11" else _branch
     # Proto: Conv3 -> ConvTranspose2d(k2,s2,bias) -> Conv3 -> Conv1
     x = _conv(feats[0], p, f"{pre}.proto.cv1", 3, eps=eps)
     x = F.conv_transpose2d(x, p[f"{pre}.proto.upsample.weight"], p[f"{pre}.proto.upsample.bias"], stride=2)
     x = _conv(x, p, f"{pre}.proto.cv2", 3, eps=eps)
     protos = _conv(x, p, f"{pre}.proto.cv3", 1, eps=eps)
     mc = torch.cat([_branch(f, p, f"{pre}.cv4.{l}", eps).view(b, cfg.nm, -1) for l, f in enumerate(feats)], 2)
-    xs = [torch.cat((_branch(f, p, f"{pre}.cv2.{l}", eps), _branch(f, p, f"{pre}.cv3.{l}", eps)), 1) for l, f in enumerate(feats)]
+    xs = [torch.cat((_branch(f, p, f"{pre}.cv2.{l}", eps), cls_branch(f, p, f"{pre}.cv3.{l}", eps)), 1) for l, f in enumerate(feats)]
     x_cat = torch.cat([xi.view(b, 4 * cfg.reg_max + cfg.nc, -1) for xi in xs], 2)
     box, cls = x_cat.split((4 * cfg.reg_max, cfg.nc), 1)
     # DFL: softmax over the 16 bins, expectation with weights arange(16)

@@ -112,3 +112,31 @@ def test_resize_oracle_against_brute_force():
     got = R.make_cropped(im, (192, 128))
     box = im[8:-8, 8:-8].astype(np.float64).reshape(192, 2, 128, 2, 3).mean((1, 3)) / 255
     assert np.abs(got - box).max() < 1e-6
+
+
+def test_yolo11_keys_shapes_and_oracle_forward():
+    """YOLO11n-seg (od_train.py:20, :55-56): key table, parameter count of the published order, finite oracle outputs"""
+    import torch
+
+    from mtgv import spec
+    from oracle import detector_ref as D
+
+    cfg = spec.yolo11_config()
+    assert cfg.arch == "11" and cfg.head_index == 23 and cfg.rep(2) == 1
+    shapes = spec.detector_param_shapes(cfg)
+    nparam = sum(int(np.prod(s)) for s in shapes.values())
+    assert 2.6e6 < nparam < 3.1e6  # published yolo11n-seg: 2.9 M parameters (80 classes)
+    for k in ("model.2.m.0.cv1.conv.weight", "model.6.m.0.m.1.cv2.conv.weight", "model.10.m.0.attn.qkv.conv.weight",
+              "model.10.m.0.attn.pe.conv.weight", "model.10.m.0.ffn.1.conv.weight", "model.23.cv3.0.0.0.conv.weight",
+              "model.23.cv3.2.1.1.conv.weight", "model.23.proto.upsample.weight"):
+        assert k in shapes, k
+    assert shapes["model.10.m.0.attn.qkv.conv.weight"] == (256, 128, 1, 1) and shapes["model.10.m.0.attn.pe.conv.weight"] == (128, 1, 3, 3)
+    assert shapes["model.2.m.0.cv1.conv.weight"] == (8, 16, 3, 3) and shapes["model.23.cv3.1.0.0.conv.weight"] == (128, 1, 3, 3)
+    # the YOLOv8 table is unchanged by the generalisation
+    assert len(spec.detector_param_shapes(spec.DetectorConfig())) == 351
+    sd = spec.random_detector_state(cfg, 3)
+    fr = np.random.default_rng(4).integers(0, 256, (1, 64, 64, 3), dtype=np.uint8)
+    small = spec.yolo11_config(imgsz=64)
+    pred, protos = D.forward(sd, small, fr)
+    assert tuple(pred.shape) == (1, 4 + cfg.nc + cfg.nm, 8 * 8 + 4 * 4 + 2 * 2) and tuple(protos.shape) == (1, 32, 16, 16)
+    assert torch.isfinite(pred).all() and torch.isfinite(protos).all()
