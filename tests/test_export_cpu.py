@@ -43,3 +43,36 @@ def test_torchscript_roundtrip(tmp_path):
     except ImportError:
         with pytest.raises(RuntimeError):
             export_onnx(cfg, sd, str(tmp_path / "enc.onnx"))
+
+
+@pytest.mark.parametrize("arch", ["v8", "11"])
+def test_detector_module_keys_and_oracle(arch, tmp_path):
+    """detector export mirror (od_export.py:163-176): ultralytics key names, same numbers as the oracle, traces"""
+    from mtgv.export_detector import DetectorModule, export_onnx as det_onnx, export_torchscript as det_ts, to_torch_module as det_module
+    from oracle import detector_ref as D
+
+    cfg = spec.yolo11_config(imgsz=64) if arch == "11" else spec.DetectorConfig(imgsz=64)
+    want = spec.detector_param_shapes(cfg)
+    have = [(k, tuple(v.shape)) for k, v in DetectorModule(cfg).state_dict().items() if not k.endswith("num_batches_tracked")]
+    assert have == [(k, tuple(s)) for k, s in want.items()]
+    sd = spec.random_detector_state(cfg, 3)
+    frames = np.random.default_rng(4).integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    ref_pred, ref_protos = D.forward(sd, cfg, frames)
+    x = D.preprocess(frames)
+    m = det_module(cfg, sd)
+    with torch.no_grad():
+        pred, protos = m(x)
+    np.testing.assert_allclose(pred.numpy(), ref_pred.numpy(), atol=2e-5)
+    np.testing.assert_allclose(protos.numpy(), ref_protos.numpy(), atol=2e-5)
+    p = str(tmp_path / "det.pt")
+    det_ts(cfg, sd, p)
+    ts = torch.jit.load(p)
+    with torch.no_grad():
+        tp, tq = ts(x)
+    np.testing.assert_allclose(tp.numpy(), pred.numpy(), atol=1e-6)
+    np.testing.assert_allclose(tq.numpy(), protos.numpy(), atol=1e-6)
+    try:
+        import onnx  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError):
+            det_onnx(cfg, sd, str(tmp_path / "det.onnx"))
