@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace mtgv {
@@ -67,6 +68,7 @@ void gemm_profile_dump(const char* path) {
             r.apro, r.grn, r.topk, pl.tm, pl.tn, pl.bk, t, fl / (t * 1e-3) / 1e12, r.bytes, r.sp);
   }
   fclose(f);
+  gemm_sp_stamps_dump((std::string(path) + ".stamps").c_str());
 }
 
 bool gemm_profile_enabled() { return g_prof.on; }

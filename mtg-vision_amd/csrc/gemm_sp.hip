@@ -5,6 +5,7 @@
 #include <string.h>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "gemm_sp_kernel.h"
 
@@ -234,6 +235,35 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
   return pl;
 }
 
+// Tuning aid: with MTGV_SP_STAMPS=1 every launch made while the launch profiler is on leaves per-tile clock stamps
+// (gemm_sp_kernel.h); gemm_sp_stamps_dump writes them next to the per-launch table (tools/sp_stamps.py reads them).
+namespace {
+struct StampRec { int M, N, K, cfg, amode, act, tiles; long* buf; };
+std::vector<StampRec> g_stamps;
+bool stamps_on() {
+  static const bool on = [] { const char* e = getenv("MTGV_SP_STAMPS"); return e != nullptr && atoi(e) != 0; }();
+  return on;
+}
+}  // namespace
+
+void gemm_sp_stamps_dump(const char* path) {
+  if (g_stamps.empty()) return;
+  HIP_OK(hipDeviceSynchronize());
+  FILE* f = fopen(path, "wb");
+  MTGV_CHECK(f != nullptr, ERR_RUNTIME, "cannot open %s", path);
+  std::vector<long> host;
+  for (const StampRec& r : g_stamps) {
+    const int hdr[8] = {r.M, r.N, r.K, r.cfg, r.amode, r.act, r.tiles, 0};
+    fwrite(hdr, sizeof(int), 8, f);
+    host.resize((size_t)r.tiles * 8);
+    HIP_OK(hipMemcpy(host.data(), r.buf, host.size() * sizeof(long), hipMemcpyDeviceToHost));
+    fwrite(host.data(), sizeof(long), host.size(), f);
+    HIP_OK(hipFree(r.buf));
+  }
+  fclose(f);
+  g_stamps.clear();
+}
+
 void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   MTGV_CHECK(pl.cfg >= 0 && pl.cfg < kNumCfg, ERR_INVALID, "gemm_sp: no plan");
   SpDev g;
@@ -274,6 +304,14 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   if (a.grn_part != nullptr)
     MTGV_CHECK(a.segmax >= (pl.unit_rows - 1) / g.hw + 2, ERR_INVALID, "gemm_sp: segmax %d too small", a.segmax);
   const int amode = a.a_fmt == 1 ? (is_conv(a) ? 2 : 0) : 1;
+  if (stamps_on() && gemm_profile_enabled()) {
+    const int tiles = pl.tiles_m * pl.tiles_n;
+    long* buf = nullptr;
+    HIP_OK(hipMalloc(&buf, (size_t)tiles * 8 * sizeof(long)));
+    HIP_OK(hipMemsetAsync(buf, 0, (size_t)tiles * 8 * sizeof(long), s));
+    g.stamps = buf;
+    g_stamps.push_back({a.M, a.N, a.K, pl.cfg, amode, a.act, tiles, buf});
+  }
   switch (pl.cfg) {
     case 0: gemm_sp_launch_cfg0(g, amode, s); break;
     case 1: gemm_sp_launch_cfg1(g, amode, s); break;

@@ -8,17 +8,34 @@ namespace mtgv {
 namespace {
 constexpr int SP_KS = 2;
 
-template <int AMODE, int ACT>
+template <int AMODE, int ACT, int EPI>
 void sp_launch_one(const SpDev& g, hipStream_t s) {
   constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN;
   constexpr size_t lds = (size_t)2 * (BM + BN) * 64 * SP_KS;
   static bool attr_done = false;
-  auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, AMODE, ACT>;
+  auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, AMODE, ACT, EPI>;
   if (!attr_done) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * SP_WM * SP_WN), lds, s, g);
+}
+
+// the compile-time epilogue shape of a launch (gemm_sp_kernel.h, EPI), or -1 when only the generic one fits
+int sp_epi_of(const SpDev& g) {
+  if (g.remap || g.N % 4 != 0) return -1;
+  return (g.out_fmt == 1 ? 1 : 0) | (g.res != nullptr ? (g.res_fmt == 1 ? 4 : 2) : 0) | (g.grn_part != nullptr ? 8 : 0);
+}
+
+// launches the instance whose EPI equals `epi` if it is one of those listed, the generic one otherwise
+template <int AMODE, int ACT>
+void sp_pick(const SpDev& g, int, hipStream_t s) {
+  sp_launch_one<AMODE, ACT, -1>(g, s);
+}
+template <int AMODE, int ACT, int E0, int... ES>
+void sp_pick(const SpDev& g, int epi, hipStream_t s) {
+  if (epi == E0) sp_launch_one<AMODE, ACT, E0>(g, s);
+  else sp_pick<AMODE, ACT, ES...>(g, epi, s);
 }
 }  // namespace
 
@@ -26,23 +43,26 @@ void sp_launch_one(const SpDev& g, hipStream_t s) {
 #define SP_CAT(a, b) SP_CAT2(a, b)
 
 // amode: 0 dense SP8 rows, 1 f32 rows through registers, 2 SP8 NHWC gather (conv)
+// Specialised epilogues: 0 f32 out; 1 SP8 out; 1|4 SP8 out + SP8 residual (detector); 2 f32 out + f32 residual
+// (pwconv2); 8 f32 out + GRN sums (pwconv1).
 void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_t s) {
+  const int epi = sp_epi_of(g);
   if (amode == 0) {
     switch (g.act) {
-      case ACT_NONE: sp_launch_one<0, ACT_NONE>(g, s); break;
-      case ACT_MISH: sp_launch_one<0, ACT_MISH>(g, s); break;
-      case ACT_GELU: sp_launch_one<0, ACT_GELU>(g, s); break;
-      case ACT_SILU: sp_launch_one<0, ACT_SILU>(g, s); break;
-      default: sp_launch_one<0, -1>(g, s); break;
+      case ACT_NONE: sp_pick<0, ACT_NONE, 0, 1>(g, epi, s); break;
+      case ACT_MISH: sp_pick<0, ACT_MISH, 8>(g, epi, s); break;
+      case ACT_GELU: sp_pick<0, ACT_GELU, 8>(g, epi, s); break;
+      case ACT_SILU: sp_pick<0, ACT_SILU, 1, 5>(g, epi, s); break;
+      default: sp_pick<0, -1>(g, epi, s); break;
     }
   } else if (amode == 1) {
-    if (g.act == ACT_NONE) sp_launch_one<1, ACT_NONE>(g, s);
-    else sp_launch_one<1, -1>(g, s);
+    if (g.act == ACT_NONE) sp_pick<1, ACT_NONE, 0, 2>(g, epi, s);
+    else sp_pick<1, -1>(g, epi, s);
   } else {
     switch (g.act) {
-      case ACT_NONE: sp_launch_one<2, ACT_NONE>(g, s); break;
-      case ACT_SILU: sp_launch_one<2, ACT_SILU>(g, s); break;
-      default: sp_launch_one<2, -1>(g, s); break;
+      case ACT_NONE: sp_pick<2, ACT_NONE, 0, 1>(g, epi, s); break;
+      case ACT_SILU: sp_pick<2, ACT_SILU, 1, 5>(g, epi, s); break;
+      default: sp_pick<2, -1>(g, epi, s); break;
     }
   }
 }

@@ -26,6 +26,8 @@
 // Products: lo*hi + hi*lo + hi*hi per k16 step into the same accumulator, k ascending: results do not depend on the
 // tile configuration.
 #pragma once
+#include <type_traits>
+
 #include "act.h"
 #include "gemm_f32.h"
 #include "sp8.h"
@@ -35,6 +37,7 @@ namespace mtgv {
 typedef float spf16 __attribute__((ext_vector_type(16)));
 
 struct SpDev {
+  long* stamps = nullptr;       // tuning aid (MTGV_SP_STAMPS): [tile][8] s_memtime at entry / first stage in / loop end / exit
   const char* A = nullptr;      // AMODE 0/2: SP8 bytes; AMODE 1: f32
   long a_rowb = 0;              // bytes per A row (pixel)
   long a_offb = 0;              // byte offset of the first channel used
@@ -67,10 +70,12 @@ struct SpDev {
 typedef const __attribute__((address_space(1))) void* sp_gptr;
 typedef __attribute__((address_space(3))) void* sp_lptr;
 
-template <int WM, int WN, int TM, int TN, int KS, int AMODE, int ACT>
+template <int WM, int WN, int TM, int TN, int KS, int AMODE, int ACT, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g) {
 #pragma clang fp contract(off)
   constexpr int NW = WM * WN, NT = 64 * NW, BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr bool GEN = EPI < 0;  // epilogue shape read from the arguments (see the epilogue)
+  static_assert(TM <= 2, "the epilogue names its slabs");
   constexpr int RB = 64 * KS, RPP = 1024 / RB, SPR = RB / 16;
   constexpr int SA = BM * RB, SB = BN * RB, STG = SA + SB;
   constexpr bool ADMA = AMODE != 1;
@@ -86,6 +91,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
+  const long st0 = g.stamps != nullptr ? (long)__builtin_amdgcn_s_memtime() : 0;
+  long st1 = 0;
   int L;
   {
     const int nwg = gridDim.x, b = blockIdx.x;
@@ -230,6 +237,34 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
 #pragma unroll
   for (int j = 0; j < TN; ++j) b_off[j] = (unsigned)(SA + (wn * TN * 32 + j * 32 + r) * RB);
 
+  // Epilogue geometry (see the epilogue): on the read-back side a lane owns columns nw0 + 32 j + 4 slot + 0..3 of
+  // every row it touches; their scales and biases are fetched now, under the main loop.
+  const int nw0 = n0 + wn * TN * 32;  // first column of this wave
+  const int mw0 = m0 + wm * TM * 32;  // first row of this wave
+  const int slot = lane & 7, lrow = lane >> 3;
+  sp_f4 wsc[TN], bsv[TN];
+  bool col_ok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw0 + j * 32 + slot * 4;
+    col_ok[j] = n < g.N;
+    sp_f4 w1 = {1.f, 1.f, 1.f, 1.f}, b0 = {0.f, 0.f, 0.f, 0.f};
+    if (n + 4 <= g.N) {
+      if (g.wscale != nullptr) w1 = *reinterpret_cast<const sp_f4*>(g.wscale + n);
+      if (g.bias != nullptr) b0 = *reinterpret_cast<const sp_f4*>(g.bias + n);
+    } else if (GEN && n < g.N) {  // ragged last quad (N % 4 != 0)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < g.N) {
+          if (g.wscale != nullptr) w1[e] = g.wscale[n + e];
+          if (g.bias != nullptr) b0[e] = g.bias[n + e];
+        }
+    }
+    wsc[j] = w1 * g.a_unmul;
+    bsv[j] = b0;
+  }
+
+
   // a wave whose rows all lie beyond M (ragged last tile, tiny-M problems) skips its MFMAs
   const bool wave_active = m0 + wm * TM * 32 < g.M;
 
@@ -242,6 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
     // The barrier also says every wave has finished reading the other buffer, which is refilled next.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (g.stamps != nullptr && t == 0) st1 = (long)__builtin_amdgcn_s_memtime();
     if (t + 1 < nk) {
       issue(t + 1, buf ^ 1);
       loadA(t + 1);
@@ -286,108 +322,83 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
     else return apply_act(x, g.act);
   };
   __builtin_amdgcn_s_barrier();  // every wave is done with the ring: it becomes the store staging area
+  const long st2 = g.stamps != nullptr ? (long)__builtin_amdgcn_s_memtime() : 0;
   if (!wave_active) return;
 
+  // The accumulators of one 32-row slab go to LDS untouched (register group gq of column block j holds columns
+  // 32 j + 8 gq + 4 h + 0..3 of row lane & 31) and are read back row-wise, 8 lanes per 128-byte row segment: a lane
+  // keeps the same 4 columns of every column block for the whole tile, so its column scale, bias and GRN sums of
+  // squares live in registers, every store instruction writes whole lines, and scale / bias / activation / residual /
+  // SP8 packing all happen on the read-back side.  Residual rows are loaded one column block ahead.
   constexpr int SROW = 128 * TN;   // bytes per staged row (32*TN floats)
-  constexpr int PPR = 8 * TN;      // 16-byte pieces per staged row
-  constexpr int WREG = 34 * SROW;  // per wave: 32 staged rows + one row of column scales + one row of biases
+  constexpr int WREG = 32 * SROW;  // per wave
   static_assert(NW * WREG <= 2 * STG, "the store staging area must fit into the ring");
   char* const stg = smem + wave * WREG;
-  const int nw0 = n0 + wn * TN * 32;  // first column of this wave
+  constexpr int NIT = 4;              // 8 rows per read-back step
 
-  // per-column constants through LDS (register group gq of column block j holds n = nw0 + 32 j + 8 gq + 4 h + 0..3;
-  // keeping all of them in registers beside the accumulators spills on the wide tiles)
-  float* const cst = reinterpret_cast<float*>(stg + 32 * SROW);
-  if (lane < PPR) {
-    const int n = nw0 + lane * 4;
-    sp_f4 w1 = {1.f, 1.f, 1.f, 1.f}, b0 = {0.f, 0.f, 0.f, 0.f};
-    if (n + 4 <= g.N) {
-      if (g.wscale != nullptr) w1 = *reinterpret_cast<const sp_f4*>(g.wscale + n);
-      if (g.bias != nullptr) b0 = *reinterpret_cast<const sp_f4*>(g.bias + n);
-    } else {  // ragged last quad (N % 4 != 0)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < g.N) {
-          if (g.wscale != nullptr) w1[e] = g.wscale[n + e];
-          if (g.bias != nullptr) b0[e] = g.bias[n + e];
-        }
-    }
-    *reinterpret_cast<sp_f4*>(cst + lane * 4) = w1 * g.a_unmul;
-    *reinterpret_cast<sp_f4*>(cst + 32 * TN + lane * 4) = b0;
-  }
-
-  const int mw0 = m0 + wm * TM * 32;  // first row of this wave
-
-  // read-back geometry: PPS lanes walk one staged row (PPS = PPR rounded up to a power of two), so a lane keeps the
-  // same 4 columns for the whole tile - its column sums of squares (GRN) need no cross-lane work until the flush
-  constexpr int PPS = PPR <= 8 ? 8 : (PPR <= 16 ? 16 : 32);
-  constexpr int RPI = 64 / PPS, NIT = 32 / RPI;
-  const int slot = lane % PPS, lrow = lane / PPS;
-  const int ncol = nw0 + slot * 4;
-  const bool col_ok = slot < PPR && ncol < g.N;
-
-  const bool grn = g.grn_part != nullptr;
+  // EPI >= 0 fixes the epilogue's shape at compile time (bit 0 SP8 output, 1 f32 residual, 2 SP8 residual, 3 GRN
+  // partial sums; no output remap, N % 4 == 0) so that the read-back loop is one straight line of code the compiler can
+  // interleave across steps; EPI < 0 reads all of it from the arguments.
+  const bool out_sp8 = GEN ? g.out_fmt == 1 : (EPI & 1) != 0;
+  const bool res_f32 = GEN ? (g.res != nullptr && g.res_fmt == 0) : (EPI & 2) != 0;
+  const bool res_sp8 = GEN ? (g.res != nullptr && g.res_fmt == 1) : (EPI & 4) != 0;
+  const bool has_res = res_f32 || res_sp8;
+  const bool remap = GEN ? g.remap : false;
+  const bool grn = GEN ? g.grn_part != nullptr : (EPI & 8) != 0;
   const int img_first = grn ? (int)fdiv((uint32_t)mw0, g.d_hw) : 0;
   const long unit = (long)tile_m * WM + wm;
-  // per-lane element offsets of row mw0 + lrow; every row this lane stores is a wave-uniform number of rows further on
-  const long o_lane = (long)(mw0 + lrow) * g.ldo + g.o_off + ncol;
-  const long r_lane = (long)(mw0 + lrow) * g.ldr + ncol;
-  const bool res_regs = g.res != nullptr && g.res_fmt == 1;  // SP8 residual: added in registers, before the split
-  const bool res_rows = g.res != nullptr && g.res_fmt == 0;  // f32 residual: added to the staged rows
-  sp_f4 run = {0.f, 0.f, 0.f, 0.f};  // sum of squares of this lane's columns over the rows of segment run_seg
-  int run_seg = 0;
-  auto flush = [&]() {
-    sp_f4 t = run;
+  // per-lane element offsets of row mw0 + lrow, column block 0; every element this lane touches is a wave-uniform
+  // number of rows and columns further on
+  const int ncol0 = nw0 + slot * 4;
+  const long o_lane = (long)(mw0 + lrow) * g.ldo + g.o_off + ncol0;
+  const long r_lane = (long)(mw0 + lrow) * g.ldr + ncol0;
+  const char* const stg_rd = stg + lrow * SROW + ((slot ^ lrow) << 4);  // + j * 128 + it * 8 * SROW
+
+  // residual pieces of column block (i, j): 16 bytes per row step (f32 quad, or the SP8 hi and lo quads)
+  auto load_res = [&](int i, int j, sp_f4 (&rr)[NIT]) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int mask = PPS; mask < 64; mask <<= 1) t[e] += __shfl_xor(t[e], mask);
-    if (lane < PPS && col_ok) *reinterpret_cast<sp_f4*>(g.grn_part + (unit * g.segmax + run_seg) * g.N + ncol) = t;
-    run = sp_f4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < NIT; ++it) {
+      rr[it] = sp_f4{0.f, 0.f, 0.f, 0.f};
+      const long e = r_lane + (long)(i * 32 + it * 8) * g.ldr + j * 32;
+      if (col_ok[j] && mw0 + i * 32 + it * 8 + lrow < g.M) {
+        if (res_f32) {
+          rr[it] = *reinterpret_cast<const sp_f4*>(reinterpret_cast<const float*>(g.res) + e);
+        } else if (res_sp8) {
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          const char* const c = reinterpret_cast<const char*>(g.res) + (e - 4 * (slot & 1)) * 4 + 8 * (slot & 1);
+          const f2 hi = *reinterpret_cast<const f2*>(c), lo = *reinterpret_cast<const f2*>(c + 16);
+          rr[it] = sp_f4{hi[0], hi[1], lo[0], lo[1]};
+        }
+      }
+    }
   };
 
+  sp_f4 run[TN];  // sums of squares of this lane's columns over the rows of segment run_seg
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int mrow = mw0 + i * 32 + r;  // this lane's row in the register stage
-    const char* const res_row =
-        res_regs ? reinterpret_cast<const char*>(g.res) + ((long)(mrow < g.M ? mrow : g.M - 1) * g.ldr) * 4 : nullptr;
+  for (int j = 0; j < TN; ++j) run[j] = sp_f4{0.f, 0.f, 0.f, 0.f};
+  int run_seg = 0;
+  auto flush = [&]() {
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      sp_f4 t = run[j];
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const sp_f4 wsc = *reinterpret_cast<const sp_f4*>(cst + j * 32 + gq * 8 + 4 * h);
-        const sp_f4 bsv = *reinterpret_cast<const sp_f4*>(cst + 32 * TN + j * 32 + gq * 8 + 4 * h);
-        sp_f4 v;
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)  // wsc is a power of two: the fused form rounds exactly like multiply-then-add
-          v[e] = activate(__builtin_fmaf(acc[i][j][4 * gq + e], wsc[e], bsv[e]));
-        if (res_regs) {
-          // this lane's 4 columns of the residual chunk: hi halves at +8h, lo halves at +16+8h of the 32-byte chunk
-          const int nq = nw0 + j * 32 + gq * 8;
-          if (nq < g.N) {
-            const char* const c = res_row + (long)nq * 4;
-            const sp_h4 rh = *reinterpret_cast<const sp_h4*>(c + 8 * h), rl = *reinterpret_cast<const sp_h4*>(c + 16 + 8 * h);
-            v = v + (__builtin_convertvector(rh, sp_f4) + __builtin_convertvector(rl, sp_f4));
-          }
-        }
-        sp_f4 piece = v;
-        if (g.out_fmt == 1) {
-          sp_h4 hi, lo;
-          sp8_split4(v, hi, lo);
-          typedef unsigned u2 __attribute__((ext_vector_type(2)));
-          const u2 a = __builtin_bit_cast(u2, hi), b = __builtin_bit_cast(u2, lo);
-          // v_permlane32_swap: lanes 32-63 of the first operand trade places with lanes 0-31 of the second
-          const auto s0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
-          const auto s1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-          // h = 0: {own hi, partner's hi} = the chunk's hi piece; h = 1: {partner's lo, own lo} = its lo piece
-          typedef unsigned u4 __attribute__((ext_vector_type(4)));
-          piece = __builtin_bit_cast(sp_f4, u4{s0[0], s1[0], s0[1], s1[1]});
-        }
-        const int sl = j * 8 + gq * 2 + h;
-        *reinterpret_cast<sp_f4*>(stg + r * SROW + ((sl ^ (r & 7)) << 4)) = piece;
-        __builtin_amdgcn_sched_barrier(0);  // one register group at a time: interleaving all of them spills on wide tiles
-      }
-    // the slab is complete in LDS (same wave wrote it; LDS operations of one wave execute in order)
+        for (int mask = 8; mask < 64; mask <<= 1) t[e] += __shfl_xor(t[e], mask);
+      if (lane < 8 && col_ok[j])
+        *reinterpret_cast<sp_f4*>(g.grn_part + (unit * g.segmax + run_seg) * g.N + ncol0 + j * 32) = t;
+      run[j] = sp_f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  sp_f4 rcur[NIT], rnext[NIT];
+  if (has_res) load_res(0, 0, rcur);
+
+  // One slab: FAST = every row and column of it exists and (GRN) all its rows belong to one image - no per-lane
+  // predicates, one basic block the compiler interleaves across steps; otherwise the masked form.
+  auto slab = [&](auto FAST_T, auto I_T) {
+    constexpr bool FAST = decltype(FAST_T)::value;
+    constexpr int i = decltype(I_T)::value;
     const int ms0 = mw0 + i * 32;
     int seg_lo = 0, seg_hi = 0;
     if (grn && ms0 < g.M) {
@@ -395,58 +406,126 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
       seg_lo = (int)fdiv((uint32_t)ms0, g.d_hw) - img_first;
       seg_hi = (int)fdiv((uint32_t)m_last, g.d_hw) - img_first;
     }
-    const bool single = seg_lo == seg_hi;
+    const bool single = FAST || seg_lo == seg_hi;
     if (grn && single && seg_lo != run_seg) {
       flush();
       run_seg = seg_lo;
     }
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = it * RPI + lrow;
-      const int m = ms0 + row;
-      if (col_ok && m < g.M) {
-        sp_f4 v = *reinterpret_cast<const sp_f4*>(stg + row * SROW + ((slot ^ (row & 7)) << 4));
-        if (grn && single) {
+    for (int j = 0; j < TN; ++j) {
+      constexpr int NB = TM * TN;
+      const int bnext = i * TN + j + 1;
+      if (has_res && bnext < NB) load_res(bnext / TN, bnext % TN, rnext);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) run[e] = __builtin_fmaf(v[e], v[e], run[e]);
+      for (int it = 0; it < NIT; ++it) {
+        const int m = ms0 + it * 8 + lrow;
+        const bool ok = FAST || (col_ok[j] && m < g.M);
+        const sp_f4 raw = *reinterpret_cast<const sp_f4*>(stg_rd + j * 128 + it * 8 * SROW);
+        sp_f4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)  // wsc is a power of two: the fused form rounds exactly like multiply-then-add
+          v[e] = activate(__builtin_fmaf(raw[e], wsc[j][e], bsv[j][e]));
+        if (grn) {
+          if (single) {
+            if (ok) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) run[j][e] = __builtin_fmaf(v[e], v[e], run[j][e]);
+            }
+          } else {  // the slab straddles images: leave the activated values in LDS for the per-image passes below
+            *reinterpret_cast<sp_f4*>(stg + (it * 8 + lrow) * SROW + (((j * 8 + slot) ^ lrow) << 4)) = v;
+          }
         }
-        const long drow = i * 32 + it * RPI;  // compile-time constant: drow * ld is scalar arithmetic
-        if (res_rows) v = v + *reinterpret_cast<const sp_f4*>(reinterpret_cast<const float*>(g.res) + r_lane + drow * g.ldr);
-        if (g.remap) {
-          const uint32_t img = fdiv((uint32_t)m, g.d_ohw);
-          const uint32_t rem = (uint32_t)m - img * (uint32_t)(g.OH * g.OW);
-          const uint32_t oh = fdiv(rem, g.d_ow);
-          const uint32_t ow = rem - oh * (uint32_t)g.OW;
-          const long orow = ((long)img * g.OH2 + oh * g.os + g.oy) * g.OW2 + ow * g.os + g.ox;
-          *reinterpret_cast<sp_f4*>(g.Out + orow * g.ldo + g.o_off + ncol) = v;
-        } else if (ncol + 4 <= g.N) {
-          *reinterpret_cast<sp_f4*>(g.Out + o_lane + drow * g.ldo) = v;
-        } else {  // ragged last quad (N % 4 != 0; f32 output without residual only)
+        if (res_f32) {
+          v = v + rcur[it];
+        } else if (res_sp8) {
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          const h4 rh = __builtin_bit_cast(h4, f2{rcur[it][0], rcur[it][1]}), rl = __builtin_bit_cast(h4, f2{rcur[it][2], rcur[it][3]});
+          v = v + (__builtin_convertvector(rh, sp_f4) + __builtin_convertvector(rl, sp_f4));
+        }
+        sp_f4 piece = v;
+        if (out_sp8) piece = __builtin_bit_cast(sp_f4, sp8_piece_from_quad(v, slot));  // every lane takes part
+        if (ok) {
+          const long drow = i * 32 + it * 8;  // compile-time constant: drow * ld is scalar arithmetic
+          if (remap) {
+            const uint32_t img = fdiv((uint32_t)m, g.d_ohw);
+            const uint32_t rem = (uint32_t)m - img * (uint32_t)(g.OH * g.OW);
+            const uint32_t oh = fdiv(rem, g.d_ow);
+            const uint32_t ow = rem - oh * (uint32_t)g.OW;
+            const long orow = ((long)img * g.OH2 + oh * g.os + g.oy) * g.OW2 + ow * g.os + g.ox;
+            *reinterpret_cast<sp_f4*>(g.Out + orow * g.ldo + g.o_off + ncol0 + j * 32) = piece;
+          } else if (!GEN || ncol0 + j * 32 + 4 <= g.N) {
+            *reinterpret_cast<sp_f4*>(g.Out + o_lane + drow * g.ldo + j * 32) = piece;
+          } else {  // ragged last quad (N % 4 != 0; f32 output without residual only)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (ncol + e < g.N) g.Out[o_lane + drow * g.ldo + e] = v[e];
+            for (int e = 0; e < 4; ++e)
+              if (ncol0 + j * 32 + e < g.N) g.Out[o_lane + drow * g.ldo + j * 32 + e] = piece[e];
+          }
         }
       }
+      if (has_res && bnext < NB) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) rcur[it] = rnext[it];
+      }
     }
-    if (grn && !single) {  // the slab straddles images: one masked pass over the staged slab per image
+    if (!FAST && grn && !single) {  // one masked pass over the staged (activated) slab per image
       for (int sgm = seg_lo; sgm <= seg_hi; ++sgm) {
         if (sgm != run_seg) {
           flush();
           run_seg = sgm;
         }
-        for (int it = 0; it < NIT; ++it) {
-          const int row = it * RPI + lrow;
-          const int m = ms0 + row;
-          if (col_ok && m < g.M && (int)fdiv((uint32_t)m, g.d_hw) - img_first == sgm) {
-            const sp_f4 v = *reinterpret_cast<const sp_f4*>(stg + row * SROW + ((slot ^ (row & 7)) << 4));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) run[e] = __builtin_fmaf(v[e], v[e], run[e]);
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int m = ms0 + it * 8 + lrow;
+            if (col_ok[j] && m < g.M && (int)fdiv((uint32_t)m, g.d_hw) - img_first == sgm) {
+              const sp_f4 v = *reinterpret_cast<const sp_f4*>(stg_rd + j * 128 + it * 8 * SROW);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) run[j][e] = __builtin_fmaf(v[e], v[e], run[j][e]);
+            }
           }
-        }
       }
+    }
+  };
+
+  const bool cols_full = nw0 + 32 * TN <= g.N && !remap;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int sl = j * 8 + gq * 2 + h;
+        *reinterpret_cast<sp_f4*>(stg + r * SROW + ((sl ^ (r & 7)) << 4)) =
+            sp_f4{acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+      }
+    // the slab is complete in LDS (same wave wrote it; LDS operations of one wave execute in order)
+    const int ms0 = mw0 + i * 32;
+    bool fast = !GEN && cols_full && ms0 + 32 <= g.M;  // the generic form keeps to the masked body (code size)
+    if (fast && grn) fast = fdiv((uint32_t)ms0, g.d_hw) == fdiv((uint32_t)(ms0 + 31), g.d_hw);
+    if constexpr (GEN) {
+      if (i == 0) slab(std::false_type{}, std::integral_constant<int, 0>{});
+      else slab(std::false_type{}, std::integral_constant<int, TM - 1>{});
+    } else if (i == 0) {
+      if (fast) slab(std::true_type{}, std::integral_constant<int, 0>{});
+      else slab(std::false_type{}, std::integral_constant<int, 0>{});
+    } else {
+      if (fast) slab(std::true_type{}, std::integral_constant<int, TM - 1>{});
+      else slab(std::false_type{}, std::integral_constant<int, TM - 1>{});
     }
   }
   if (grn) flush();
+  if (g.stamps != nullptr && wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile's stores have been accepted
+    const long st3 = (long)__builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      long* d = g.stamps + (long)blockIdx.x * 8;
+      d[0] = st0, d[1] = st1, d[2] = st2, d[3] = st3;
+      d[4] = (long)__builtin_amdgcn_s_getreg((15 << 11) | 4);   // HW_ID[15:0]: wave slot, SIMD, pipe, CU, SH, SE
+      d[5] = (long)__builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID[3:0]
+    }
+  }
 }
 
 }  // namespace mtgv
