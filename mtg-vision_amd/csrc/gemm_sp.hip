@@ -218,6 +218,8 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
   if (best < 0) {
     for (int c = 0; c < kNumCfg; ++c) {
       const SpCfg& k = kCfg[c];
+      // the 1 KB-per-stage multiplier image of the f32-by-DMA A path does not fit beside the 128 x 192 ring twice per CU
+      if (c == 1 && !sp8_in && a.a_scale != nullptr) continue;
       const long tiles = (long)ceil_div(a.M, k.bm()) * ceil_div(a.N, k.bn());
       // two blocks per CU: a "round" is up to 512 tiles, each CU working on two at half speed
       const double rounds = (double)((tiles + 511) / 512);
@@ -303,7 +305,13 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   g.os = a.os, g.oy = a.oy, g.ox = a.ox, g.OH2 = a.OH2, g.OW2 = a.OW2;
   if (a.grn_part != nullptr)
     MTGV_CHECK(a.segmax >= (pl.unit_rows - 1) / g.hw + 2, ERR_INVALID, "gemm_sp: segmax %d too small", a.segmax);
-  const int amode = a.a_fmt == 1 ? (is_conv(a) ? 2 : 0) : 1;
+  // f32 A: by DMA and split at the fragment read when the rows are 16-byte aligned, need no range multiplier and a
+  // tile's rows span at most 8 images of the per-image multipliers; through registers otherwise
+  int amode = a.a_fmt == 1 ? (is_conv(a) ? 2 : 0) : 1;
+  if (amode == 1 && g.a_mul == 1.0f && ((uintptr_t)g.A & 15) == 0) {
+    if (g.a_scale == nullptr) amode = 4;
+    else if (((uintptr_t)g.a_scale & 15) == 0 && (kCfg[pl.cfg].bm() - 1) / g.hw + 2 <= 8) amode = 3;
+  }
   if (stamps_on() && gemm_profile_enabled()) {
     const int tiles = pl.tiles_m * pl.tiles_n;
     long* buf = nullptr;

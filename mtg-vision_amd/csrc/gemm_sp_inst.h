@@ -11,7 +11,7 @@ constexpr int SP_KS = 2;
 template <int AMODE, int ACT, int EPI>
 void sp_launch_one(const SpDev& g, hipStream_t s) {
   constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN;
-  constexpr size_t lds = (size_t)2 * (BM + BN) * 64 * SP_KS;
+  constexpr size_t lds = (size_t)2 * ((BM + BN) * 64 * SP_KS + (AMODE == 3 ? 1024 : 0));
   static bool attr_done = false;
   auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, AMODE, ACT, EPI>;
   if (!attr_done) {
@@ -42,7 +42,8 @@ void sp_pick(const SpDev& g, int epi, hipStream_t s) {
 #define SP_CAT2(a, b) a##b
 #define SP_CAT(a, b) SP_CAT2(a, b)
 
-// amode: 0 dense SP8 rows, 1 f32 rows through registers, 2 SP8 NHWC gather (conv)
+// amode: 0 dense SP8 rows, 1 f32 rows through registers, 2 SP8 NHWC gather (conv), 3 / 4 f32 rows by DMA with /
+// without per-image multipliers
 // Specialised epilogues: 0 f32 out; 1 SP8 out; 1|4 SP8 out + SP8 residual (detector); 2 f32 out + f32 residual
 // (pwconv2); 8 f32 out + GRN sums (pwconv1).
 void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_t s) {
@@ -56,8 +57,14 @@ void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_
       default: sp_pick<0, -1>(g, epi, s); break;
     }
   } else if (amode == 1) {
-    if (g.act == ACT_NONE) sp_pick<1, ACT_NONE, 0, 2>(g, epi, s);
+    if (g.act == ACT_NONE) sp_pick<1, ACT_NONE>(g, epi, s);
     else sp_pick<1, -1>(g, epi, s);
+  } else if (amode == 3) {
+    if (g.act == ACT_NONE) sp_pick<3, ACT_NONE, 2>(g, epi, s);
+    else sp_pick<3, -1>(g, epi, s);
+  } else if (amode == 4) {
+    if (g.act == ACT_NONE) sp_pick<4, ACT_NONE, 0, 2>(g, epi, s);
+    else sp_pick<4, -1>(g, epi, s);
   } else {
     switch (g.act) {
       case ACT_NONE: sp_pick<2, ACT_NONE, 0, 1>(g, epi, s); break;

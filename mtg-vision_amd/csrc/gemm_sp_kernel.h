@@ -77,8 +77,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   constexpr bool GEN = EPI < 0;  // epilogue shape read from the arguments (see the epilogue)
   static_assert(TM <= 2, "the epilogue names its slabs");
   constexpr int RB = 64 * KS, RPP = 1024 / RB, SPR = RB / 16;
-  constexpr int SA = BM * RB, SB = BN * RB, STG = SA + SB;
   constexpr bool ADMA = AMODE != 1;
+  constexpr bool AF32 = AMODE == 3 || AMODE == 4;  // f32 rows by DMA, split into hi / lo when a fragment is read
+  constexpr int SA = BM * RB, SB = BN * RB, SSC = AMODE == 3 ? 1024 : 0, STG = SA + SB + SSC;
+  static_assert(AMODE != 3 || KS == 2, "the scale image is one DMA piece: 8 images x 32 k");
   constexpr int PA = ADMA ? BM / RPP : 0, PB = BN / RPP, NP = PA + PB;
   constexpr int PPW = (NP + NW - 1) / NW;
   constexpr int CPS = BM * 2 * KS;                  // REG: 8-float chunks of A per stage
@@ -140,6 +142,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
     }
     tailz[u] = ktail && ((nk - 1) * 2 * KS + (slot >> 1)) >= kchunks;
   }
+  // AMODE 3: lane l of the scale piece fetches 16 bytes (4 k) of image img0 + l / 8
+  const int img0 = AMODE == 3 ? (int)fdiv((uint32_t)m0, g.d_hw) : 0;
+  const char* sc_src = nullptr;
+  bool sc_tailz = false;
+  if constexpr (AMODE == 3) {
+    const int img_last = (int)fdiv((uint32_t)(g.M - 1), g.d_hw);
+    const int im = img0 + (lane >> 3) < img_last ? img0 + (lane >> 3) : img_last;
+    sc_src = reinterpret_cast<const char*>(g.a_scale + (long)im * g.K) + (lane & 7) * 16;
+    sc_tailz = ktail && ((nk - 1) * 2 * KS + ((lane & 7) >> 1)) >= kchunks;
+  }
   auto issue = [&](int t, int buf) {
 #pragma unroll
     for (int u = 0; u < PPW; ++u) {
@@ -163,6 +175,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
         }
         // A pieces fill [0, SA), B pieces [SA, STG) (in REG mode the A region is written by ds_write instead)
         __builtin_amdgcn_global_load_lds((sp_gptr)s, (sp_lptr)(smem + buf * STG + (SA - PA * 1024) + p * 1024), 16, 0, 0);
+      }
+    }
+    if constexpr (AMODE == 3) {  // the stage's slice of the per-image A multipliers: [8 images from img0][32 k]
+      if (wave == NP % NW) {
+        const char* sp = sc_src + (long)t * RB;
+        if (t == nk - 1 && sc_tailz) sp = g.zero;
+        __builtin_amdgcn_global_load_lds((sp_gptr)sp, (sp_lptr)(smem + buf * STG + SA + SB), 16, 0, 0);
       }
     }
   };
@@ -236,6 +255,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   for (int i = 0; i < TM; ++i) a_off[i] = (unsigned)((wm * TM * 32 + i * 32 + r) * RB);
 #pragma unroll
   for (int j = 0; j < TN; ++j) b_off[j] = (unsigned)(SA + (wn * TN * 32 + j * 32 + r) * RB);
+  unsigned sc_off[TM];  // AMODE 3: this lane's row of the scale image, at its half of the k step
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    sc_off[i] = 0;
+    if constexpr (AMODE == 3) {
+      int m = m0 + wm * TM * 32 + i * 32 + r;
+      m = m < g.M ? m : g.M - 1;
+      sc_off[i] = (unsigned)(SA + SB + ((int)fdiv((uint32_t)m, g.d_hw) - img0) * 128 + h * 32);
+    }
+  }
 
   // Epilogue geometry (see the epilogue): on the read-back side a lane owns columns nw0 + 32 j + 4 slot + 0..3 of
   // every row it touches; their scales and biases are fetched now, under the main loop.
@@ -291,8 +320,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
         sp_h8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          ah[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + shi);
-          al[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + slo);
+          if constexpr (AF32) {  // 8 consecutive k of row r as f32: (scale,) split, and the fragments are ready
+            sp_f4 x0 = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + shi);
+            sp_f4 x1 = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + slo);
+            if constexpr (AMODE == 3) {
+              x0 = x0 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
+              x1 = x1 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
+            }
+            sp8_split8(x0, x1, ah[i], al[i]);
+          } else {
+            ah[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + shi);
+            al[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + slo);
+          }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
