@@ -34,6 +34,29 @@ def test_encoder_batch256_consistency_and_oracle_sample():
     assert np.abs(z[idx].cpu().numpy() - ref).max() < 1e-4
 
 
+def test_plain_tiny_batch256_at_224_config2():
+    """BASELINE.json configs[1] as written: plain ConvNeXt-V2 tiny, batch 256 at 224x224 - determinism, batch
+    independence and a 4-image sample within 1e-4 of the CPU oracle (the oracle takes seconds per image at this size)."""
+    from mtgv import spec
+    from mtgv.encoder import Encoder
+    from oracle import encoder_ref as R
+
+    cfg = spec.encoder_config("convnextv2_tiny", (224, 224))
+    sd = spec.random_encoder_state(cfg, 5)
+    enc = Encoder(cfg, sd, max_batch=256)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.randint(0, 256, (256, 224, 224, 3), generator=g, device="cuda", dtype=torch.uint8)
+    z = enc.encode(x)
+    assert z.shape == (256, cfg.z_size) and torch.isfinite(z).all()
+    assert torch.equal(z, enc.encode(x))
+    z_small = torch.cat([enc.encode(x[i : i + 64]) for i in range(0, 256, 64)])
+    assert (z - z_small).abs().max().item() < 1e-5
+    idx = [0, 85, 170, 255]
+    f = (x[idx].cpu().numpy().astype(np.float32) / 255.0).transpose(0, 3, 1, 2)
+    ref = R.encoder_forward(sd, cfg, f).numpy()
+    assert np.abs(z[idx].cpu().numpy() - ref).max() < 1e-4
+
+
 def test_detector_batch32_equals_single_frames():
     """conv outputs have no cross-row reduction: a frame's detections are bit-identical alone or in a batch of 32"""
     from mtgv import spec

@@ -14,6 +14,8 @@ def short(name):
     name = re.sub(r"^void ", "", name)
     if "gemm_f32_kernel" in name:
         return "gemm_f32_kernel"
+    if "gemm_sp_kernel" in name:
+        return "gemm_sp_kernel"
     return re.sub(r"\(.*$", "", name)[:48]
 
 
@@ -26,5 +28,5 @@ for c in tot:
 kern = {}
 for k in sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"]), key=lambda k: -(2 * tot["FETCH_SIZE"][k] + tot["WRITE_SIZE"][k])):
     kern[k] = {"read_bytes_per_step": int(2 * tot["FETCH_SIZE"][k] * 1024 / steps), "write_bytes_per_step": int(tot["WRITE_SIZE"][k] * 1024 / steps)}
-g = kern.get("gemm_f32_kernel", {"read_bytes_per_step": 0, "write_bytes_per_step": 0})
-print(json.dumps({"precision": tag, "kernels": kern, "hbm_bytes_per_step": g["read_bytes_per_step"] + g["write_bytes_per_step"]}, indent=1))
+gemm = sum(kern[k]["read_bytes_per_step"] + kern[k]["write_bytes_per_step"] for k in ("gemm_f32_kernel", "gemm_sp_kernel") if k in kern)
+print(json.dumps({"precision": tag, "kernels": kern, "hbm_bytes_per_step": gemm}, indent=1))
