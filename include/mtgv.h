@@ -42,15 +42,21 @@ MTGV_API int mtgv_device_count(void);
 
 /* Operand precision of every GEMM-shaped kernel launch of the process (convs, linears, mask and bank GEMMs).
  *   MTGV_PREC_F32   (0)  f32 operands on the f32-input matrix instruction (exact products).
- *   MTGV_PREC_F16X3 (1)  each f32 operand split on the fly into fp16 hi + lo; three fp16 matrix instructions per
- *                        product, f32 accumulate.  Error vs fp64 at the f32 level, ~2x the GEMM rate; operands
- *                        must lie inside the fp16 range (|x| <= 65504), larger values turn into inf.
+ *   MTGV_PREC_F16X3 (1)  each f32 operand represented as fp16 hi + lo; three fp16 matrix instructions per
+ *                        product, f32 accumulate.  Error vs fp64 at the f32 level, ~2x the GEMM rate.  Weights carry
+ *                        a power-of-two scale per output row (undone in the accumulator), so their magnitude does
+ *                        not matter; activations inside the handles are O(1) by construction; the single-op entry
+ *                        points (mtgv_op_*) rescale inputs beyond 2^14 by a power of two.  Values that still leave
+ *                        the fp16 range turn into inf - visible, never silently wrong.
  * The initial value comes from the environment (MTGV_GEMM_PREC=f32|f16x3, default f16x3).  Both
  * meet the path's 1e-4 contract against the reference (tests/test_gpu_precision.py).  Not thread-safe: set it
  * before the worker threads start.
- * Note for F16X3 (measured on MI355X / ROCm 7.2): kernels of OTHER code that use packed-FP32
- * arithmetic (v_pk_mul_f32, v_pk_fma_f32) and run on another stream of the same GPU at the same time can get wrong
- * lanes; this library itself is built without those instructions.  Use F32 when foreign kernels share the GPU. */
+ * Concurrency contract for F16X3 (measured on MI355X / ROCm 7.2): kernels that use packed-FP32
+ * arithmetic (v_pk_mul_f32, v_pk_fma_f32) and run on ANOTHER STREAM of the same GPU while F16X3 launches are in
+ * flight can get wrong lanes.  This library is built without those instructions and by itself keeps every launch
+ * on the caller's stream (mtgv.Pipeline overlaps two streams only with MTGV_OVERLAP=on, and then runs nothing but
+ * library kernels on them).  A caller that runs foreign kernels (PyTorch elementwise ops included) concurrently on
+ * a second stream must either serialise them against the library's stream or select MTGV_PREC_F32. */
 #define MTGV_PREC_F32 0
 #define MTGV_PREC_F16X3 1
 MTGV_API int mtgv_set_gemm_precision(int32_t prec);

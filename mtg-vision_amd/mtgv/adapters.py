@@ -276,7 +276,7 @@ class CardSegmenter:
                     raise FileNotFoundError("CardSegmenter: no model_path given (the reference's hard-coded default path does not exist here)")
                 state_dict = torch.load(model_path, map_location="cpu", weights_only=True)
                 state_dict = state_dict.get("state_dict", state_dict) if isinstance(state_dict, dict) else state_dict
-            self.yolo = Detector(spec.DetectorConfig(), state_dict, max_batch=max_batch)
+            self.yolo = Detector(spec.detector_config_for_state(state_dict), state_dict, max_batch=max_batch)  # v8n-seg or 11n-seg
 
     def __call__(self, rgb_im: np.ndarray) -> list[InstanceSeg]:
         img, ratio, (left, top) = letterbox(rgb_im, self.yolo.cfg.imgsz)

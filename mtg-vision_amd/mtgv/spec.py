@@ -335,6 +335,17 @@ def yolo11_config(**kw) -> DetectorConfig:
     return DetectorConfig(arch="11", depth=0.50, **kw)
 
 
+def detector_config_for_state(state_dict, **kw) -> DetectorConfig:
+    """The scale-"n" family a ultralytics `state_dict` belongs to, from its key set: YOLO11-seg has its Segment head at
+    index 23 (`model.23.*`; C2PSA at 10), YOLOv8-seg at 22.  `nc` is read from the class branch's last conv."""
+    keys = list(state_dict.keys())
+    head = 23 if any(k.startswith("model.23.") for k in keys) else 22
+    w = state_dict.get(f"model.{head}.cv3.0.2.weight")
+    if w is not None:
+        kw.setdefault("nc", int(w.shape[0]))
+    return yolo11_config(**kw) if head == 23 else DetectorConfig(**kw)
+
+
 # ---- YOLO11n-seg graph (ultralytics cfg/models/11/yolo11-seg.yaml, scale "n") ----------
 # C3k2(cout, n, c3k, e) | C2PSA(cout, n); the rest as above.  [external - recalled from ultralytics 8.3.x]
 def yolo11_seg_graph(cfg: DetectorConfig):

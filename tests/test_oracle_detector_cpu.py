@@ -140,3 +140,12 @@ def test_yolo11_keys_shapes_and_oracle_forward():
     pred, protos = D.forward(sd, small, fr)
     assert tuple(pred.shape) == (1, 4 + cfg.nc + cfg.nm, 8 * 8 + 4 * 4 + 2 * 2) and tuple(protos.shape) == (1, 32, 16, 16)
     assert torch.isfinite(pred).all() and torch.isfinite(protos).all()
+
+
+def test_detector_config_for_state_picks_family_and_nc():
+    from mtgv import spec
+
+    for cfg in (spec.DetectorConfig(nc=3), spec.yolo11_config(nc=5)):
+        sd = spec.random_detector_state(cfg, 0)
+        got = spec.detector_config_for_state(sd)
+        assert got.arch == cfg.arch and got.nc == cfg.nc and got.depth == cfg.depth
