@@ -7,13 +7,16 @@ namespace mtgv {
 
 namespace {
 constexpr int SP_KS = 2;
+#ifndef SP_NST
+#define SP_NST 2
+#endif
 
 template <int AMODE, int ACT, int EPI>
 void sp_launch_one(const SpDev& g, hipStream_t s) {
   constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN;
-  constexpr size_t lds = (size_t)2 * ((BM + BN) * 64 * SP_KS + (AMODE == 3 ? 1024 : 0));
+  constexpr size_t lds = (size_t)SP_NST * ((BM + BN) * 64 * SP_KS + (AMODE == 3 ? 1024 : 0));
   static bool attr_done = false;
-  auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, AMODE, ACT, EPI>;
+  auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, SP_NST, AMODE, ACT, EPI>;
   if (!attr_done) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -57,8 +60,12 @@ void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_
       default: sp_pick<0, -1>(g, epi, s); break;
     }
   } else if (amode == 1) {
+#if SP_NST == 2
     if (g.act == ACT_NONE) sp_pick<1, ACT_NONE>(g, epi, s);
     else sp_pick<1, -1>(g, epi, s);
+#else
+    MTGV_CHECK(false, ERR_RUNTIME, "gemm_sp: the register A path has no deep-ring instance");
+#endif
   } else if (amode == 3) {
     if (g.act == ACT_NONE) sp_pick<3, ACT_NONE, 2>(g, epi, s);
     else sp_pick<3, -1>(g, epi, s);

@@ -4,7 +4,7 @@
 //   Out[orow(m)][o_off + n] = act( sum_k A(m,k) * W[n][k] * wscale[n] + bias[n] ) (+ res[m][n])
 //
 // Block: WM x WN waves; wave tile (32*TM) rows x (32*TN) columns; K in stages of 16*KS (RB = 64*KS bytes per staged
-// row), two LDS buffers, one raw s_barrier per stage.
+// row), a ring of NST LDS buffers (NST - 1 stages in flight), one raw s_barrier per stage.
 //   B (weights)          always by LDS-DMA (global_load_lds_dwordx4) from the registered SP8 copy.
 //   A, AMODE 0 (DMA)     SP8 activation rows written by the producer kernel: LDS-DMA.  Dense rows [M][lda].
 //   A, AMODE 2 (CONV)    SP8 NHWC activations gathered by the DMA's per-lane source address (implicit GEMM, no
@@ -70,12 +70,13 @@ struct SpDev {
 typedef const __attribute__((address_space(1))) void* sp_gptr;
 typedef __attribute__((address_space(3))) void* sp_lptr;
 
-template <int WM, int WN, int TM, int TN, int KS, int AMODE, int ACT, int EPI>
+template <int WM, int WN, int TM, int TN, int KS, int NST, int AMODE, int ACT, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g) {
 #pragma clang fp contract(off)
   constexpr int NW = WM * WN, NT = 64 * NW, BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr bool GEN = EPI < 0;  // epilogue shape read from the arguments (see the epilogue)
   static_assert(TM <= 2, "the epilogue names its slabs");
+  static_assert(NST >= 2 && NST <= 4 && (AMODE != 1 || NST == 2), "ring depth; the register A path is two-deep");
   constexpr int RB = 64 * KS, RPP = 1024 / RB, SPR = RB / 16;
   constexpr bool ADMA = AMODE != 1;
   constexpr bool AF32 = AMODE == 3 || AMODE == 4;  // f32 rows by DMA, split into hi / lo when a fragment is read
@@ -297,18 +298,41 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   // a wave whose rows all lie beyond M (ragged last tile, tiny-M problems) skips its MFMAs
   const bool wave_active = m0 + wm * TM * 32 < g.M;
 
-  issue(0, 0);
+  // DMA pieces this wave issues per stage: the waits below count them (vmcnt retires in order)
+  int my_pieces = 0;
+#pragma unroll
+  for (int u = 0; u < PPW; ++u) my_pieces += (NP % NW == 0 || wave + NW * u < NP) ? 1 : 0;
+  if (AMODE == 3 && wave == NP % NW) my_pieces += 1;
+  constexpr int AHEAD = NST - 2;  // stages that may still be in flight when stage t is consumed
+  auto wait_stage = [&](bool tail) {
+    // steady state: everything but the AHEAD youngest stages has landed; near the end fewer stages are outstanding
+    // than that, so the tail waits for all of them
+    if (AHEAD == 0 || tail) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else if (my_pieces == PPW) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW * AHEAD) : "memory");
+    } else if (my_pieces == PPW + 1) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((PPW + 1) * AHEAD) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((PPW > 1 ? PPW - 1 : 0) * AHEAD) : "memory");
+    }
+  };
+
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nk) issue(s0, s0);
   loadA(0);
   storeA(0);
-  int buf = 0;
+  int buf = 0;                      // ring slot of stage t
+  int nbuf = NST - 1;               // ring slot of stage t + NST - 1
   for (int t = 0; t < nk; ++t) {
     // stage t landed: this wave's DMA pieces (vmcnt) and REG-mode ds_writes (lgkmcnt), then everyone's (barrier).
-    // The barrier also says every wave has finished reading the other buffer, which is refilled next.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // The barrier also says every wave has finished reading the slot of stage t - 1, which is refilled next.
+    wait_stage(t + NST - 1 > nk);
     __builtin_amdgcn_s_barrier();
     if (g.stamps != nullptr && t == 0) st1 = (long)__builtin_amdgcn_s_memtime();
-    if (t + 1 < nk) {
-      issue(t + 1, buf ^ 1);
+    if (t + NST - 1 < nk) {
+      issue(t + NST - 1, nbuf);
       loadA(t + 1);
     }
     if (wave_active) {
@@ -348,8 +372,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
           }
       }
     }
-    if (t + 1 < nk) storeA(buf ^ 1);
-    buf ^= 1;
+    if (AMODE == 1 && t + 1 < nk) storeA(buf ^ 1);
+    buf = buf + 1 == NST ? 0 : buf + 1;
+    nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
   }
 
   // ---- epilogue ----
@@ -371,7 +396,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   // SP8 packing all happen on the read-back side.  Residual rows are loaded one column block ahead.
   constexpr int SROW = 128 * TN;   // bytes per staged row (32*TN floats)
   constexpr int WREG = 32 * SROW;  // per wave
-  static_assert(NW * WREG <= 2 * STG, "the store staging area must fit into the ring");
+  static_assert(NW * WREG <= NST * STG, "the store staging area must fit into the ring");
   char* const stg = smem + wave * WREG;
   constexpr int NIT = 4;              // 8 rows per read-back step
 
