@@ -462,8 +462,12 @@ void Encoder::body(int n, float* z_out, hipStream_t s) {
     if (st > 0) {
       // LayerNorm(channels_first) + Conv2d(k2, s2): convnextv2.py:258-263
       const int hp = sh_[st - 1], wp = sw_[st - 1], cp = d[st - 1];
-      ln_rows_launch(cur, cp, 0, alt, cp, 0, ds_ln_w_[st], ds_ln_b_[st], (long)n * hp * wp, cp, 1e-6f, s);
+      // the LayerNorm writes hi/lo-split rows when the conv runs on the LDS-DMA kernel (its 2x2 gather is then a DMA
+      // source address, no conversion in the loader)
+      const int fmt = gemm_sp_takes_sp8(ds_w_[st], n * h * w, c, 4 * cp, cp, 0) ? 1 : 0;
+      ln_rows_launch(cur, cp, 0, alt, cp, 0, ds_ln_w_[st], ds_ln_b_[st], (long)n * hp * wp, cp, 1e-6f, s, fmt);
       GemmArgs g;
+      g.a_fmt = fmt;
       g.A = alt;
       g.W = ds_w_[st];
       g.bias = ds_b_[st];
