@@ -35,7 +35,7 @@ FLAGS = [
     "-Wno-unused-result",
     # No packed-FP32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 ...) in device code.  Measured on MI355X: a wave
     # executing them beside the split-precision GEMM of another stream (v_cvt_pk_f16_f32 + f16 MFMA on the same SIMD)
-    # sporadically lost the low half of a packed result in one 16-lane group (tools/debug/determinism_probe5.py:
+    # sporadically lost the low half of a packed result in one 16-lane group (tests/test_gpu_overlap.py:
     # 14/30 wrong blocks with, 0/90 without).  The flag only exists for the device target; the host pass ignores it.
     "-Xclang",
     "-target-feature",

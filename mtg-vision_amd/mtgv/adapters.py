@@ -62,21 +62,8 @@ class CoreMlEncoder:
 # ---------------------------------------------------------------------------
 # detector: mtgvision/od_export.py:18-160
 # ---------------------------------------------------------------------------
-def _largest_contour(mask: np.ndarray) -> np.ndarray:
-    """Outer boundary (x, y) of the largest 8-connected blob of a binary mask, Moore tracing.
-
-    Stands in for ultralytics' `masks.xy` (cv2.findContours RETR_EXTERNAL / CHAIN_APPROX_SIMPLE, largest
-    contour).  cv2 is absent: parity unpinned; "next" row of SURVEY.md section 8f."""
-    m = np.pad(mask.astype(bool), 1)
-    if not m.any():
-        return np.zeros((0, 2), np.float32)
-    # label by flood fill over rows (scipy is importable but keep this dependency-free and simple)
-    from scipy import ndimage
-
-    lab, n = ndimage.label(m, structure=np.ones((3, 3), int))
-    if n > 1:
-        sizes = ndimage.sum(m, lab, index=np.arange(1, n + 1))
-        m = lab == (1 + int(np.argmax(sizes)))
+def _trace_blob(m: np.ndarray) -> np.ndarray:
+    """Moore boundary trace of the single 8-connected blob in the padded boolean image `m`: (P, 2) array of (y, x)"""
     ys, xs = np.nonzero(m)
     start = (int(ys[0]), int(xs[ys == ys[0]].min()))
     nbrs = [(0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1)]  # clockwise from west
@@ -95,8 +82,55 @@ def _largest_contour(mask: np.ndarray) -> np.ndarray:
         if not found or cur == start:
             break
         pts.append(cur)
-    p = np.asarray(pts, np.float32)[:, ::-1] - 1.0  # (x, y), undo the padding
-    return p
+    return np.asarray(pts, np.int64)
+
+
+def _chain_approx_simple(pts: np.ndarray) -> np.ndarray:
+    """cv2.CHAIN_APPROX_SIMPLE: drop the interior points of horizontal, vertical and diagonal runs of a closed chain"""
+    n = len(pts)
+    if n <= 2:
+        return pts
+    d_in = pts - np.roll(pts, 1, axis=0)
+    d_out = np.roll(pts, -1, axis=0) - pts
+    keep = np.any(d_in != d_out, axis=1)
+    return pts[keep] if keep.any() else pts[:1]
+
+
+def _mask_segments(mask: np.ndarray, strategy: str = "all") -> np.ndarray:
+    """ultralytics `masks.xy` for one binary mask (`ops.masks2segments`, called behind od_export.py:152-153): the outer
+    boundaries of its 8-connected blobs as cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) reports them - run end
+    points only - and, with strategy "all" (ultralytics' default), every blob's points concatenated (blobs in raster
+    order of their first pixel); "largest" keeps the contour with the most points.  (x, y) float32.
+    cv2 / ultralytics are absent: parity unpinned; recent ultralytics additionally re-orders the concatenation so that
+    the joined outline does not cross itself, which changes neither the point set nor its hull."""
+    m = np.pad(np.asarray(mask).astype(bool), 1)
+    if not m.any():
+        return np.zeros((0, 2), np.float32)
+    from scipy import ndimage
+
+    lab, n = ndimage.label(m, structure=np.ones((3, 3), int))
+    segs = [_chain_approx_simple(_trace_blob(lab == i)) for i in range(1, n + 1)]
+    if strategy == "largest":
+        segs = [segs[int(np.argmax([len(x) for x in segs]))]]
+    elif strategy != "all":
+        raise ValueError(f"unknown strategy {strategy!r}")
+    p = np.concatenate(segs).astype(np.float32)
+    return p[:, ::-1] - 1.0  # (x, y), undo the padding
+
+
+def _largest_contour(mask: np.ndarray) -> np.ndarray:
+    """Every boundary pixel (x, y) of the largest 8-connected blob of a binary mask, in trace order (test helper and
+    the dense form of `_mask_segments(mask, "largest")`)."""
+    m = np.pad(np.asarray(mask).astype(bool), 1)
+    if not m.any():
+        return np.zeros((0, 2), np.float32)
+    from scipy import ndimage
+
+    lab, n = ndimage.label(m, structure=np.ones((3, 3), int))
+    if n > 1:
+        sizes = ndimage.sum(m, lab, index=np.arange(1, n + 1))
+        m = lab == (1 + int(np.argmax(sizes)))
+    return _trace_blob(m).astype(np.float32)[:, ::-1] - 1.0
 
 
 def _convex_hull(points: np.ndarray) -> np.ndarray:
@@ -300,7 +334,7 @@ class CardSegmenter:
         if det.mask_logits is not None and det.conf.numel() > 0:
             masks = binarize_masks(det.mask_logits).cpu().numpy()
             for m, conf in zip(masks, det.conf.cpu().numpy()):
-                pts = _largest_contour(m)
+                pts = _mask_segments(m)  # masks.xy: all blobs' outlines, run end points
                 if len(pts) == 0:
                     continue
                 pts = (pts - np.asarray([left, top], np.float32)) / np.float32(ratio)  # scale_coords back to the frame

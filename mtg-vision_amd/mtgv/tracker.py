@@ -8,8 +8,10 @@ cards and join their payloads.  Differences, all on the host side:
 * all tracks due for an update are embedded in ONE encoder batch and matched in ONE bank pass per frame (the
   reference issues one CoreML call and one Qdrant round trip per track, server.py:182-190); the results are the same.
 * association: the reference uses `norfair.Tracker(mean_euclidean, distance_threshold=300, hit_counter_max=5,
-  initialization_delay=2)` (server.py:100-106).  norfair is third-party and absent, so `MeanEuclideanTracker` states the
-  same policy without the Kalman filter (a track's position is its last matched detection): PARITY UNPINNED.
+  initialization_delay=2)` (server.py:100-106).  norfair is third-party and absent; `KalmanPointTracker` restates its
+  published algorithm - per-coordinate constant-velocity Kalman filter with norfair's default parameters, detections
+  matched greedily against the predicted positions, hit counters (-1 per frame, +2 per hit, capped), ids handed out after
+  the initialisation delay: PARITY UNPINNED.  `MeanEuclideanTracker` is the same policy without the filter.
 * JPEG thumbnails (`encode_rgb_im`, server.py:223-226) use Pillow instead of cv2.
 """
 
@@ -135,6 +137,103 @@ class MeanEuclideanTracker:
         return sorted(out)
 
 
+class _KalmanTrack:
+    """One tracked object: norfair's `TrackedObject` with its default `OptimizedKalmanFilter` (R 4, Q 0.1, position
+    variance 10, velocity variance 1), i.e. an independent [position, velocity] filter per coordinate with F = [[1, 1],
+    [0, 1]], Q = q I, H = [1, 0]; the covariance is propagated inside `update`, `predict` only moves the state."""
+
+    R, Q, POS_VAR, VEL_VAR = 4.0, 0.1, 10.0, 1.0
+
+    def __init__(self, points: np.ndarray, period: int, initialization_delay: int):
+        z = np.asarray(points, np.float64).reshape(-1)
+        self.shape = np.asarray(points).shape
+        self.pos, self.vel = z.copy(), np.zeros_like(z)
+        self.pp = np.full_like(z, self.POS_VAR)
+        self.pv = np.zeros_like(z)
+        self.vv = np.full_like(z, self.VEL_VAR)
+        self.hit_counter = period
+        self.is_initializing = self.hit_counter <= initialization_delay
+        self.id: Optional[int] = None
+        self.last_detection = -1
+
+    @property
+    def estimate(self) -> np.ndarray:
+        return self.pos.reshape(self.shape)
+
+    def step(self):
+        self.hit_counter -= 1
+        self.pos = self.pos + self.vel  # filter.predict()
+
+    def kalman_update(self, points: np.ndarray):
+        z = np.asarray(points, np.float64).reshape(-1)
+        e = z - self.pos
+        s = self.pp + 2.0 * self.pv + self.vv + self.Q + self.R  # innovation variance of the predicted state
+        k0, k1 = 1.0 - self.R / s, (self.pv + self.vv) / s
+        self.pos = self.pos + k0 * e
+        self.vel = self.vel + k1 * e
+        self.pp, self.pv, self.vv = k0 * self.R, k1 * self.R, self.vv + self.Q - k1 * k1 * s
+
+
+class KalmanPointTracker:
+    """`norfair.Tracker(distance_function=mean_euclidean, distance_threshold, hit_counter_max, initialization_delay)`
+    restated (server.py:100-106): every frame each object loses a hit and moves by its velocity; detections are matched
+    to the predicted corner positions, closest pair first, first against the initialised objects and then against the
+    initialising ones; a hit adds 2 (capped at `hit_counter_max`) and feeds the filter; an object gets its id once its
+    counter exceeds the initialisation delay and is dropped when the counter falls below zero."""
+
+    def __init__(self, distance_threshold: float = 300.0, hit_counter_max: int = 5, initialization_delay: int = 2, period: int = 1):
+        self.distance_threshold = float(distance_threshold)
+        self.hit_counter_max = int(hit_counter_max)
+        self.initialization_delay = int(initialization_delay)
+        self.period = int(period)
+        self.tracks: list[_KalmanTrack] = []
+        self._next_id = 1
+
+    def _match(self, objs: list[_KalmanTrack], dets: list[np.ndarray], free: list[int]) -> list[int]:
+        pairs = []
+        for oi, o in enumerate(objs):
+            for di in free:
+                dist = float(np.linalg.norm(np.asarray(dets[di], np.float64) - o.estimate, axis=1).mean())
+                if dist < self.distance_threshold:
+                    pairs.append((dist, oi, di))
+        pairs.sort()
+        used_o, used_d = set(), set()
+        for _, oi, di in pairs:
+            if oi in used_o or di in used_d:
+                continue
+            used_o.add(oi)
+            used_d.add(di)
+            o = objs[oi]
+            o.last_detection = di
+            o.hit_counter = min(o.hit_counter + 2 * self.period, self.hit_counter_max)
+            if o.is_initializing and o.hit_counter > self.initialization_delay:
+                o.is_initializing = False
+                o.id = self._next_id
+                self._next_id += 1
+            o.kalman_update(dets[di])
+        return [di for di in free if di not in used_d]
+
+    def update(self, detections: list[np.ndarray]) -> list[tuple[int, int]]:
+        """detections: list of (P, 2) point sets -> [(track id, detection index)] for the initialised tracks that were
+        matched in this frame, in track-id order (the reference skips tracks running on predictions, server.py:155-156)."""
+        self.tracks = [t for t in self.tracks if t.hit_counter >= 0]
+        for t in self.tracks:
+            t.last_detection = -1
+            t.step()
+        free = list(range(len(detections)))
+        free = self._match([t for t in self.tracks if not t.is_initializing], detections, free)
+        free = self._match([t for t in self.tracks if t.is_initializing], detections, free)
+        for di in free:
+            t = _KalmanTrack(detections[di], self.period, self.initialization_delay)
+            if not t.is_initializing:
+                t.id = self._next_id
+                self._next_id += 1
+            t.last_detection = di
+            self.tracks.append(t)
+        out = [(t.id, t.last_detection) for t in self.tracks if t.id is not None and t.last_detection >= 0 and t.hit_counter >= 0]
+        return sorted(out)
+
+
 class TrackerCtx:
     def __init__(self, update_wait_sec: float = 0.5, ewma_weight: float = 0.1, *, segmenter, encoder, vecs, data=None,
                  clock: Callable[[], float] = time.time, thumbnails: bool = True):
@@ -146,7 +245,7 @@ class TrackerCtx:
         self.segmenter, self.encoder, self.vecs, self.data = segmenter, encoder, vecs, data
         self.clock = clock
         self.thumbnails = thumbnails
-        self.tracker = MeanEuclideanTracker(distance_threshold=300, hit_counter_max=5, initialization_delay=2)
+        self.tracker = KalmanPointTracker(distance_threshold=300, hit_counter_max=5, initialization_delay=2)
         self.tracked_data: dict[int, TrackedData] = {}
 
     def _embed(self, crops: list[np.ndarray]) -> np.ndarray:

@@ -99,6 +99,35 @@ def test_linear_ex_grn_paths_random():
         assert ((got - want).abs() / (want.abs() + 1e-3)).max().item() < 1e-5, (case, hw, nimg, n, k)
 
 
+@pytest.mark.parametrize("hw,nimg,n,k", [(49, 37, 96, 392), (196, 9, 192, 776), (784, 3, 96, 384), (49, 130, 768, 3080), (24, 50, 64, 72)])
+def test_linear_ex_scaled_a_with_residual_pwconv2_shapes(hw, nimg, n, k):
+    """pwconv2-shaped launches through the f32-by-DMA A path: per-image multipliers as an LDS image, images that straddle
+    tiles (49 and 24 rows per image: up to 4 / 7 images per 128-row tile), K tails (k % 32 != 0), ragged last tile,
+    f32 residual"""
+    from mtgv import native as nv
+
+    rng = np.random.default_rng(hw * 1000 + k)
+    L = nv.lib()
+    m = hw * nimg
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((m, n)).astype(np.float32)
+    sc = (rng.random((nimg, k)) + 0.5).astype(np.float32)
+    out = torch.full((m, n), float("nan"), device="cuda")
+    A, W, B, R, SC = _dev(a), _dev(w), _dev(b), _dev(r), _dev(sc)
+    nv.check(L.mtgv_op_linear_ex(nv.ptr(A), nv.ptr(W), nv.ptr(B), nv.ptr(R), nv.ptr(out), m, n, k, 0, hw, nv.ptr(SC), None, None, nv.stream()))
+    a2 = torch.from_numpy(a).double() * torch.from_numpy(sc).double().repeat_interleave(hw, 0)
+    ref = F.linear(a2, torch.from_numpy(w).double(), torch.from_numpy(b).double()) + torch.from_numpy(r).double()
+    assert torch.isfinite(out).all()
+    assert (out.cpu().double() - ref).abs().max().item() < 5e-5
+    # and without multipliers (plain f32 rows by DMA)
+    out.fill_(float("nan"))
+    nv.check(L.mtgv_op_linear_ex(nv.ptr(A), nv.ptr(W), nv.ptr(B), nv.ptr(R), nv.ptr(out), m, n, k, 0, hw, None, None, None, nv.stream()))
+    ref = F.linear(torch.from_numpy(a).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double()) + torch.from_numpy(r).double()
+    assert (out.cpu().double() - ref).abs().max().item() < 5e-5
+
+
 def test_conv_random_geometry():
     from mtgv import native as nv
 

@@ -113,3 +113,38 @@ def test_agrees_with_host_orient(ang):
     seg = InstanceSeg(points=_largest_contour(m), label=0, conf=1.0)
     host = np.asarray(seg.xyxyxyxy, np.float64)
     assert ok == 1 and np.abs(q - host).max() <= 1.5, f"{q} vs {host}"
+
+
+def _shoelace(p):
+    x, y = p[:, 0].astype(np.float64), p[:, 1].astype(np.float64)
+    return 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(np.roll(x, -1), y))
+
+
+def test_mask_segments_are_run_end_points_of_every_blob():
+    """`masks.xy` stand-in (adapters._mask_segments): CHAIN_APPROX_SIMPLE keeps run end points only - same polygon as
+    the dense trace; strategy "all" concatenates every blob, "largest" keeps one; the hull is that of all mask pixels"""
+    from mtgv.adapters import _convex_hull, _largest_contour, _mask_segments
+
+    rect = np.zeros((40, 50), bool)
+    rect[5:21, 7:31] = True
+    seg = _mask_segments(rect)
+    assert sorted(map(tuple, seg.tolist())) == [(7.0, 5.0), (7.0, 20.0), (30.0, 5.0), (30.0, 20.0)]
+    m, _ = _rot_rect_mask(160, 160, 80, 80, 50, 72, 33, notch=0.3)
+    dense, simple = _largest_contour(m), _mask_segments(m)
+    assert len(simple) < len(dense) and set(map(tuple, simple.tolist())) <= set(map(tuple, dense.tolist()))
+    assert abs(_shoelace(simple) - _shoelace(dense)) < 1e-9
+    two = m.copy()
+    two[4:12, 4:9] = True  # a second, small blob
+    both, one = _mask_segments(two, "all"), _mask_segments(two, "largest")
+    assert len(both) == len(one) + 4 and (both[:4].max(0) <= [8, 11]).all()  # raster order: the small blob comes first
+    pix = np.argwhere(two)[:, ::-1].astype(np.float64)
+    assert set(map(tuple, _convex_hull(both).tolist())) == set(map(tuple, _convex_hull(pix).tolist()))
+    with pytest.raises(ValueError):
+        _mask_segments(two, "longest")
+    assert _mask_segments(np.zeros((5, 5), bool)).shape == (0, 2)
+    # the GPU / oracle quad takes the hull of all mask pixels: same quad as the host statement on masks.xy("all")
+    from mtgv.adapters import InstanceSeg
+
+    q, ok = Q.mask_quad(two)
+    host = np.asarray(InstanceSeg(points=both, label=0, conf=1.0).xyxyxyxy, np.float64)
+    assert ok == 1 and np.abs(q - host).max() <= 1.5

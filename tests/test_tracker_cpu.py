@@ -92,3 +92,56 @@ def test_color_and_thumbnail():
     assert get_color(1) == get_color("1") and get_color(1) != get_color(2) and len(get_color(7)) == 7
     s = encode_rgb_im(np.zeros((8, 8, 3), np.uint8))
     assert s is None or isinstance(s, str)
+
+
+def test_kalman_track_equals_matrix_filter():
+    """the per-coordinate closed form is the textbook filter with F = [[1,1],[0,1]], Q = q I, H = [1,0], R = r"""
+    from mtgv.tracker import _KalmanTrack
+
+    rng = np.random.default_rng(0)
+    z0 = rng.uniform(0, 500, (4, 2))
+    t = _KalmanTrack(z0, 1, 2)
+    F = np.asarray([[1.0, 1.0], [0.0, 1.0]])
+    x = np.stack([z0.reshape(-1), np.zeros(8)])          # (2, 8): one filter per coordinate
+    P = np.tile(np.asarray([[10.0, 0.0], [0.0, 1.0]])[:, :, None], (1, 1, 8))
+    for step in range(12):
+        z = z0 + 7.0 * (step + 1) + rng.normal(0, 2, (4, 2))
+        t.step()
+        t.kalman_update(z)
+        x = F @ x
+        for c in range(8):
+            Pp = F @ P[:, :, c] @ F.T + 0.1 * np.eye(2)
+            S = Pp[0, 0] + 4.0
+            K = Pp[:, 0] / S
+            x[:, c] = x[:, c] + K * (z.reshape(-1)[c] - x[0, c])
+            P[:, :, c] = Pp - np.outer(K, Pp[0, :])
+        assert np.allclose(t.pos, x[0], atol=1e-9) and np.allclose(t.vel, x[1], atol=1e-9)
+        assert np.allclose(t.pp, P[0, 0], atol=1e-9) and np.allclose(t.pv, P[0, 1], atol=1e-9) and np.allclose(t.vv, P[1, 1], atol=1e-9)
+
+
+def test_kalman_tracker_counters_prediction_and_ids():
+    from mtgv.tracker import KalmanPointTracker
+
+    sq = np.asarray([[0, 0], [100, 0], [100, 140], [0, 140]], np.float64)
+    trk = KalmanPointTracker(distance_threshold=300, hit_counter_max=5, initialization_delay=2)
+    # ids after the third consecutive detection (counter 1 -> 2 -> 3 > delay), as norfair with these settings
+    assert trk.update([sq]) == [] and trk.update([sq + 10]) == []
+    assert trk.update([sq + 20]) == [(1, 0)]
+    # a second card far away gets its own id; association follows the predicted (moving) positions, not the last ones
+    far = sq + 1000
+    for k in range(3, 9):
+        out = trk.update([far, sq + 10 * k])
+    assert sorted(out) == [(1, 1), (2, 0)]
+    est = trk.tracks[0].estimate
+    assert np.abs(est - (sq + 80)).max() < 8.0 and np.all(trk.tracks[0].vel > 5.0)  # velocity learnt (10 px / frame)
+    # misses: the counter (5 at most) drops by one per frame; the track survives exactly hit_counter_max + 1 empty frames
+    for k in range(5):
+        assert trk.update([]) == []
+        assert any(t.id == 1 for t in trk.tracks)
+    trk.update([])
+    trk.update([])
+    assert not any(t.id == 1 for t in trk.tracks)
+    # a card crossing during the gap re-enters as a new object with a new id
+    for _ in range(3):
+        out = trk.update([sq])
+    assert out == [(3, 0)]
