@@ -113,6 +113,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   const char* src[PPW];   // dense A / B: address of the lane's slot in stage 0.  CONV A: pixel (img, 0, 0) of the row
   bool tailz[PPW];
   int cslot[PPW], cih0[PPW], ciw0[PPW];  // CONV A pieces: logical slot, first input row / column of the window
+  const char* csrc[PPW];             // CONV A pieces, fast form: address of the window's first pixel at this lane's chunk
+  const bool conv_fast = AMODE == 2 && g.Cin % (16 * KS) == 0;
 #pragma unroll
   for (int u = 0; u < PPW; ++u) {
     const int p = wave + NW * u;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
     const int row = pp * RPP + lane / SPR;
     const int sw = KS == 2 ? (row >> 1) & 7 : (row >> 2) & 3;
     const int slot = (lane % SPR) ^ sw;
-    cslot[u] = slot, cih0[u] = 0, ciw0[u] = 0;
+    cslot[u] = slot, cih0[u] = 0, ciw0[u] = 0, csrc[u] = nullptr;
     if (isA) {
       int m = m0 + row;
       m = m < g.M ? m : g.M - 1;
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
         const uint32_t ow = rem - oh * (uint32_t)g.OW;
         cih0[u] = (int)oh * g.stride - g.pad;
         ciw0[u] = (int)ow * g.stride - g.pad;
+        csrc[u] = g.A + (((long)img * g.H + cih0[u]) * g.Wd + ciw0[u]) * g.a_rowb + g.a_offb + slot * 16;
         src[u] = g.A + (long)img * g.H * g.Wd * g.a_rowb + g.a_offb + (slot & 1) * 16;
       } else {
         src[u] = g.A + (long)m * g.a_rowb + g.a_offb + slot * 16;
@@ -159,7 +162,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
       const int p = wave + NW * u;
       if (NP % NW == 0 || p < NP) {
         const char* s;
-        if (AMODE == 2 && p < PA) {
+        if (AMODE == 2 && p < PA && conv_fast) {
+          // Cin is a multiple of the stage depth: the whole stage lies inside one tap, so tap, kh, kw and the first
+          // channel are wave-uniform (scalar registers) and a lane only tests its pixel against the padding
+          const uint32_t k0 = (uint32_t)t * (16u * KS);
+          const uint32_t tap = fdiv(k0, g.d_cin);
+          const uint32_t kh = fdiv(tap, g.d_kw);
+          const uint32_t kw = tap - kh * (uint32_t)g.KW;
+          const long tap_off = ((long)kh * g.Wd + kw) * g.a_rowb + (long)(k0 - tap * (uint32_t)g.Cin) * 4;
+          const bool ok = (unsigned)(cih0[u] + (int)kh) < (unsigned)g.H && (unsigned)(ciw0[u] + (int)kw) < (unsigned)g.Wd;
+          s = ok ? csrc[u] + tap_off : g.zero;
+        } else if (AMODE == 2 && p < PA) {
           // chunk -> (tap, channel); the tap's pixel may fall into the zero padding
           const int kc = t * 2 * KS + (cslot[u] >> 1);
           const uint32_t k = (uint32_t)(kc < kchunks ? kc : 0) * 8u;
