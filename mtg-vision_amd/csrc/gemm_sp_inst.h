@@ -14,11 +14,17 @@ constexpr int SP_KS = 2;
 template <int AMODE, int ACT, int EPI>
 void sp_launch_one(const SpDev& g, hipStream_t s) {
   constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN;
-  constexpr size_t lds = (size_t)SP_NST * ((BM + BN) * 64 * SP_KS + (AMODE == 3 ? 1024 : 0));
+  constexpr size_t ring = (size_t)SP_NST * ((AMODE == 5 ? BN : BM + BN) * 64 * SP_KS + (AMODE == 3 ? 1024 : 0));
+  size_t lds = ring;
+  if (AMODE == 5) {  // window of BM + 2 W + 2 pixels x 128 B in front of the weight ring; the epilogue stages 32 rows per wave
+    const size_t win = (size_t)((BM + 2 * g.Wd + 2 + 7) & ~7) * 128;
+    const size_t stage = (size_t)SP_WM * SP_WN * 32 * 128 * SP_TN;
+    lds = win + ring > stage ? win + ring : stage;
+  }
   static bool attr_done = false;
   auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, SP_NST, AMODE, ACT, EPI>;
   if (!attr_done) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AMODE == 5 ? 160 * 1024 : (int)lds));
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * SP_WM * SP_WN), lds, s, g);
@@ -46,7 +52,7 @@ void sp_pick(const SpDev& g, int epi, hipStream_t s) {
 #define SP_CAT(a, b) SP_CAT2(a, b)
 
 // amode: 0 dense SP8 rows, 1 f32 rows through registers, 2 SP8 NHWC gather (conv), 3 / 4 f32 rows by DMA with /
-// without per-image multipliers
+// without per-image multipliers, 5 SP8 3x3 stride-1 conv out of a staged input window
 // Specialised epilogues: 0 f32 out; 1 SP8 out; 1|4 SP8 out + SP8 residual (detector); 2 f32 out + f32 residual
 // (pwconv2); 8 f32 out + GRN sums (pwconv1).
 void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_t s) {
@@ -72,6 +78,15 @@ void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_
   } else if (amode == 4) {
     if (g.act == ACT_NONE) sp_pick<4, ACT_NONE, 0, 2>(g, epi, s);
     else sp_pick<4, -1>(g, epi, s);
+  } else if (amode == 5) {
+#if SP_NST == 2
+    switch (g.act) {
+      case ACT_SILU: sp_pick<5, ACT_SILU, 1, 5>(g, epi, s); break;
+      default: sp_pick<5, -1>(g, epi, s); break;
+    }
+#else
+    MTGV_CHECK(false, ERR_RUNTIME, "gemm_sp: the window conv has no deep-ring instance");
+#endif
   } else {
     switch (g.act) {
       case ACT_NONE: sp_pick<2, ACT_NONE, 0, 1>(g, epi, s); break;

@@ -78,9 +78,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   static_assert(TM <= 2, "the epilogue names its slabs");
   static_assert(NST >= 2 && NST <= 4 && (AMODE != 1 || NST == 2), "ring depth; the register A path is two-deep");
   constexpr int RB = 64 * KS, RPP = 1024 / RB, SPR = RB / 16;
-  constexpr bool ADMA = AMODE != 1;
+  constexpr bool AWIN = AMODE == 5;  // 3x3 / stride 1 / pad 1 conv: the tile's input window is staged once per 32 channels
+  constexpr bool ADMA = AMODE != 1 && !AWIN;
   constexpr bool AF32 = AMODE == 3 || AMODE == 4;  // f32 rows by DMA, split into hi / lo when a fragment is read
-  constexpr int SA = BM * RB, SB = BN * RB, SSC = AMODE == 3 ? 1024 : 0, STG = SA + SB + SSC;
+  constexpr int SA = AWIN ? 0 : BM * RB, SB = BN * RB, SSC = AMODE == 3 ? 1024 : 0, STG = SA + SB + SSC;
+  static_assert(!AWIN || (KS == 2 && NST == 2), "window conv: 32-channel stages, two-deep weight ring");
   static_assert(AMODE != 3 || KS == 2, "the scale image is one DMA piece: 8 images x 32 k");
   constexpr int PA = ADMA ? BM / RPP : 0, PB = BN / RPP, NP = PA + PB;
   constexpr int PPW = (NP + NW - 1) / NW;
@@ -156,6 +158,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
     sc_src = reinterpret_cast<const char*>(g.a_scale + (long)im * g.K) + (lane & 7) * 16;
     sc_tailz = ktail && ((nk - 1) * 2 * KS + ((lane & 7) >> 1)) >= kchunks;
   }
+  // AWIN: [window: win_px pixels x 128 B][weight ring]; otherwise the ring starts at the base
+  const int win_px = AWIN ? ((BM + 2 * g.Wd + 2 + 7) & ~7) : 0;
+  char* const ring = smem + (AWIN ? win_px * 128 : 0);
   auto issue = [&](int t, int buf) {
 #pragma unroll
     for (int u = 0; u < PPW; ++u) {
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
           if (t == nk - 1 && tailz[u]) s = g.zero;
         }
         // A pieces fill [0, SA), B pieces [SA, STG) (in REG mode the A region is written by ds_write instead)
-        __builtin_amdgcn_global_load_lds((sp_gptr)s, (sp_lptr)(smem + buf * STG + (SA - PA * 1024) + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((sp_gptr)s, (sp_lptr)(ring + buf * STG + (SA - PA * 1024) + p * 1024), 16, 0, 0);
       }
     }
     if constexpr (AMODE == 3) {  // the stage's slice of the per-image A multipliers: [8 images from img0][32 k]
@@ -248,12 +253,39 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
           sp8_split8(ra[v][0] * rs[v][0] * g.a_mul, ra[v][1] * rs[v][1] * g.a_mul, hi, lo);
         else
           sp8_split8(ra[v][0] * g.a_mul, ra[v][1] * g.a_mul, hi, lo);
-        char* const d = smem + buf * STG;
+        char* const d = ring + buf * STG;
         *reinterpret_cast<sp_h8*>(d + a_lds[v]) = hi;
         *reinterpret_cast<sp_h8*>(d + (a_lds[v] ^ 16u)) = lo;
       }
     }
   };
+
+  // AWIN: window pixel w holds input pixel m0 - Wd - 1 + w (output and input share the linear (img, y, x) index:
+  // stride 1, pad 1); pieces of 8 pixels x 128 B, 16-byte slots swizzled by the pixel like the rows of a dense A stage
+  auto issue_window = [&](int cc) {
+    if constexpr (AWIN) {
+      for (int pw = wave; pw < (win_px >> 3); pw += NW) {
+        const int w = pw * 8 + (lane >> 3);
+        const long gp = (long)m0 - g.Wd - 1 + w;
+        const int slot = (lane & 7) ^ ((w >> 1) & 7);
+        const char* sp = (gp >= 0 && gp < (long)g.M) ? g.A + gp * g.a_rowb + g.a_offb + cc * 128 + slot * 16 : g.zero;
+        __builtin_amdgcn_global_load_lds((sp_gptr)sp, (sp_lptr)(smem + pw * 1024), 16, 0, 0);
+      }
+    }
+  };
+  int wy[TM], wx[TM];  // AWIN: (y, x) of this lane's output pixels
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    wy[i] = wx[i] = 0;
+    if constexpr (AWIN) {
+      int m = m0 + wm * TM * 32 + i * 32 + r;
+      m = m < g.M ? m : g.M - 1;
+      const uint32_t img = fdiv((uint32_t)m, g.d_ohw);
+      const uint32_t rem = (uint32_t)m - img * (uint32_t)(g.OH * g.OW);
+      wy[i] = (int)fdiv(rem, g.d_ow);
+      wx[i] = (int)(rem - (uint32_t)wy[i] * (uint32_t)g.OW);
+    }
+  }
 
   spf16 acc[TM][TN];
 #pragma unroll
@@ -331,63 +363,125 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
     }
   };
 
+  if constexpr (AWIN) {
+    // per 32-channel slice: stage the window once, then 9 taps x 2 k-steps out of it while the taps' weight stages
+    // ring through two buffers.  Accumulation order: channel slice outer, tap inner.
+    const int ncc = g.Cin >> 5;
+    const char* const win = smem;
+    int buf = 0;
+    issue(0, 0);  // weights of (slice 0, tap 0): K index of (tap, slice) is tap * Cin + 32 * slice
+    for (int cc = 0; cc < ncc; ++cc) {
+      __builtin_amdgcn_s_barrier();  // every wave is done with the previous slice's window
+      issue_window(cc);
+      for (int tap = 0; tap < 9; ++tap) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g.stamps != nullptr && cc == 0 && tap == 0) st1 = (long)__builtin_amdgcn_s_memtime();
+        if (tap < 8) issue((tap + 1) * ncc + cc, buf ^ 1);
+        else if (cc + 1 < ncc) issue(cc + 1, buf ^ 1);
+        if (wave_active) {
+          const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+          const int shift = g.Wd + 1 + dy * g.Wd + dx;
+          const char* const sb = ring + buf * STG;
+          unsigned w_off[TM], w_sw[TM];
+          bool w_ok[TM];
 #pragma unroll
-  for (int s0 = 0; s0 < NST - 1; ++s0)
-    if (s0 < nk) issue(s0, s0);
-  loadA(0);
-  storeA(0);
-  int buf = 0;                      // ring slot of stage t
-  int nbuf = NST - 1;               // ring slot of stage t + NST - 1
-  for (int t = 0; t < nk; ++t) {
-    // stage t landed: this wave's DMA pieces (vmcnt) and REG-mode ds_writes (lgkmcnt), then everyone's (barrier).
-    // The barrier also says every wave has finished reading the slot of stage t - 1, which is refilled next.
-    wait_stage(t + NST - 1 > nk);
-    __builtin_amdgcn_s_barrier();
-    if (g.stamps != nullptr && t == 0) st1 = (long)__builtin_amdgcn_s_memtime();
-    if (t + NST - 1 < nk) {
-      issue(t + NST - 1, nbuf);
-      loadA(t + 1);
-    }
-    if (wave_active) {
-      const char* const sb = smem + buf * STG;
+          for (int i = 0; i < TM; ++i) {
+            const int w = wm * TM * 32 + i * 32 + r + shift;
+            w_off[i] = (unsigned)w * 128u;
+            w_sw[i] = (unsigned)(w >> 1) & 7u;
+            w_ok[i] = (unsigned)(wy[i] + dy) < (unsigned)g.H && (unsigned)(wx[i] + dx) < (unsigned)g.Wd;
+          }
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const unsigned shi = (unsigned)(((ks * 4 + h * 2 + 0) ^ swr) << 4);
-        const unsigned slo = (unsigned)(((ks * 4 + h * 2 + 1) ^ swr) << 4);
-        sp_h8 ah[TM], al[TM], bh[TN], bl[TN];
+          for (int ks = 0; ks < KS; ++ks) {
+            const unsigned shi = (unsigned)(((ks * 4 + h * 2 + 0) ^ swr) << 4);
+            const unsigned slo = (unsigned)(((ks * 4 + h * 2 + 1) ^ swr) << 4);
+            sp_h8 ah[TM], al[TM], bh[TN], bl[TN];
+            const sp_h8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          if constexpr (AF32) {  // 8 consecutive k of row r as f32: (scale,) split, and the fragments are ready
-            sp_f4 x0 = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + shi);
-            sp_f4 x1 = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + slo);
-            if constexpr (AMODE == 3) {
-              x0 = x0 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
-              x1 = x1 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
+            for (int i = 0; i < TM; ++i) {
+              const sp_h8 vh = *reinterpret_cast<const sp_h8*>(win + w_off[i] + (((ks * 4 + h * 2 + 0) ^ w_sw[i]) << 4));
+              const sp_h8 vl = *reinterpret_cast<const sp_h8*>(win + w_off[i] + (((ks * 4 + h * 2 + 1) ^ w_sw[i]) << 4));
+              ah[i] = w_ok[i] ? vh : z8;  // zero padding: the tap's pixel lies outside the image
+              al[i] = w_ok[i] ? vl : z8;
             }
-            sp8_split8(x0, x1, ah[i], al[i]);
-          } else {
-            ah[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + shi);
-            al[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + slo);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              bh[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + shi);
+              bl[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int i = 0; i < TM; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+              }
           }
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          bh[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + shi);
-          bl[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {  // small cross terms first, the hi*hi product last
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-          }
+        buf ^= 1;
       }
     }
-    if (AMODE == 1 && t + 1 < nk) storeA(buf ^ 1);
-    buf = buf + 1 == NST ? 0 : buf + 1;
-    nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+  } else {
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+      if (s0 < nk) issue(s0, s0);
+    loadA(0);
+    storeA(0);
+    int buf = 0;                      // ring slot of stage t
+    int nbuf = NST - 1;               // ring slot of stage t + NST - 1
+    for (int t = 0; t < nk; ++t) {
+      // stage t landed: this wave's DMA pieces (vmcnt) and REG-mode ds_writes (lgkmcnt), then everyone's (barrier).
+      // The barrier also says every wave has finished reading the slot of stage t - 1, which is refilled next.
+      wait_stage(t + NST - 1 > nk);
+      __builtin_amdgcn_s_barrier();
+      if (g.stamps != nullptr && t == 0) st1 = (long)__builtin_amdgcn_s_memtime();
+      if (t + NST - 1 < nk) {
+        issue(t + NST - 1, nbuf);
+        loadA(t + 1);
+      }
+      if (wave_active) {
+        const char* const sb = ring + buf * STG;
+  #pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const unsigned shi = (unsigned)(((ks * 4 + h * 2 + 0) ^ swr) << 4);
+          const unsigned slo = (unsigned)(((ks * 4 + h * 2 + 1) ^ swr) << 4);
+          sp_h8 ah[TM], al[TM], bh[TN], bl[TN];
+  #pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            if constexpr (AF32) {  // 8 consecutive k of row r as f32: (scale,) split, and the fragments are ready
+              sp_f4 x0 = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + shi);
+              sp_f4 x1 = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + slo);
+              if constexpr (AMODE == 3) {
+                x0 = x0 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
+                x1 = x1 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
+              }
+              sp8_split8(x0, x1, ah[i], al[i]);
+            } else {
+              ah[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + shi);
+              al[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + slo);
+            }
+          }
+  #pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + shi);
+            bl[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
+          }
+  #pragma unroll
+          for (int j = 0; j < TN; ++j)
+  #pragma unroll
+            for (int i = 0; i < TM; ++i) {  // small cross terms first, the hi*hi product last
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+      if (AMODE == 1 && t + 1 < nk) storeA(buf ^ 1);
+      buf = buf + 1 == NST ? 0 : buf + 1;
+      nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+    }
   }
 
   // ---- epilogue ----
@@ -409,7 +503,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   // SP8 packing all happen on the read-back side.  Residual rows are loaded one column block ahead.
   constexpr int SROW = 128 * TN;   // bytes per staged row (32*TN floats)
   constexpr int WREG = 32 * SROW;  // per wave
-  static_assert(NW * WREG <= NST * STG, "the store staging area must fit into the ring");
+  static_assert(AWIN || NW * WREG <= NST * STG, "the store staging area must fit into the ring");  // AWIN: the host sizes LDS for it
   char* const stg = smem + wave * WREG;
   constexpr int NIT = 4;              // 8 rows per read-back step
 
