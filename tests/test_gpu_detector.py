@@ -203,3 +203,44 @@ def test_no_detections_and_other_nc():
     assert np.abs(pred.cpu().numpy()[:, 4:] - rp.numpy()[:, 4:]).max() < 1e-4
     assert np.abs(pred.cpu().numpy()[:, :4] - rp.numpy()[:, :4]).max() < 640 * 1e-4
     assert np.abs(protos.cpu().numpy() - rq.numpy()).max() < 1e-4
+
+
+_WINDOW_SCRIPT = r"""
+import os, sys, numpy as np, torch
+sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "mtg-vision_amd")]
+from mtgv import spec
+from mtgv.detector import Detector
+arch = sys.argv[2]
+cfg = spec.yolo11_config() if arch == "11" else spec.DetectorConfig()
+det = Detector(cfg, spec.random_detector_state(cfg, 3), max_batch=3)
+g = torch.Generator(device="cuda").manual_seed(9)
+frames = torch.randint(0, 256, (3, 640, 640, 3), generator=g, device="cuda", dtype=torch.uint8)
+det.forward(frames, False, 0)
+pred, protos = det.raw_outputs(3)
+np.savez(sys.argv[1], pred=pred.cpu().numpy(), protos=protos.cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("arch", ["v8", "11"])
+def test_window_conv_agrees_with_tap_gather(tmp_path, arch):
+    """3x3 / stride-1 convs run out of the LDS-staged input window (gemm_sp_kernel A mode 5); MTGV_SP_WINDOW=0 keeps the
+    nine-tap gather.  Same network, same inputs, batch 3 (ragged last tiles on the 20x20 and 40x40 maps): the raw head
+    outputs agree to rounding (the two forms accumulate K in a different order).  Fresh processes: the switch is read once."""
+    import os
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    script.write_text(_WINDOW_SCRIPT)
+    outs = []
+    for flag in ("1", "0"):
+        out = tmp_path / f"w{flag}.npz"
+        env = dict(os.environ, MTGV_SP_WINDOW=flag)
+        r = subprocess.run([sys.executable, str(script), str(out), arch], env=env, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    for k in ("pred", "protos"):
+        a, b = outs[0][k].astype(np.float64), outs[1][k].astype(np.float64)
+        assert np.isfinite(a).all() and a.shape == b.shape
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), k
