@@ -273,6 +273,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
       }
     }
   };
+  // The first stages are requested now, before the rest of the set-up (accumulators, fragment offsets, epilogue
+  // constants): their latency runs under it.
+  if constexpr (AWIN) {
+    issue(0, 0);  // weights of (slice 0, tap 0): K index of (tap, slice) is tap * Cin + 32 * slice
+    issue_window(0);
+  } else {
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+      if (s0 < nk) issue(s0, s0);
+    loadA(0);
+  }
   int wy[TM], wx[TM];  // AWIN: (y, x) of this lane's output pixels
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -369,10 +380,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
     const int ncc = g.Cin >> 5;
     const char* const win = smem;
     int buf = 0;
-    issue(0, 0);  // weights of (slice 0, tap 0): K index of (tap, slice) is tap * Cin + 32 * slice
     for (int cc = 0; cc < ncc; ++cc) {
-      __builtin_amdgcn_s_barrier();  // every wave is done with the previous slice's window
-      issue_window(cc);
+      if (cc > 0) {
+        __builtin_amdgcn_s_barrier();  // every wave is done with the previous slice's window
+        issue_window(cc);
+      }
       for (int tap = 0; tap < 9; ++tap) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -424,10 +436,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
       }
     }
   } else {
-#pragma unroll
-    for (int s0 = 0; s0 < NST - 1; ++s0)
-      if (s0 < nk) issue(s0, s0);
-    loadA(0);
     storeA(0);
     int buf = 0;                      // ring slot of stage t
     int nbuf = NST - 1;               // ring slot of stage t + NST - 1
