@@ -53,11 +53,12 @@ def group_launches(recs, nprof, precision):
             g = "det3x3" if int(r["KH"]) == 3 else "det1x1"
         else:
             g = "enc_other"
-        d = out.setdefault(g, {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
+        d = out.setdefault(g, {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0, "fill": 0.0})
         d["launches"] += 1
         d["ms"] += float(r["ms"])
         d["flop"] += 2.0 * int(r["M"]) * int(r["N"]) * int(r["K"]) * int(r["batch"])
         d["bytes"] += float(r.get("bytes", 0) or 0)
+        d["fill"] += float(r.get("fill", 0) or 0)
     peak = PEAK_MFMA_TFLOPS[precision]
     mult = MFMA_FLOPS_PER_FLOP[precision]
     res = {}
@@ -71,6 +72,8 @@ def group_launches(recs, nprof, precision):
             "issued_mfma_frac": round(tf * mult / peak, 4),
             "compulsory_gbs": round(d["bytes"] / sec / 1e9, 1) if sec > 0 else 0.0,
             "hbm_frac": round(d["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4) if sec > 0 else 0.0,
+            # what the tiles of the group pull through L2 into LDS (every tile its A and B panels), per second
+            "lds_fill_tbs": round(d["fill"] / sec / 1e12, 2) if sec > 0 else 0.0,
         }
     return res
 
@@ -255,7 +258,7 @@ def main():
         ms, fl, nl, by = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_double(0)
         native.check(L.mtgv_profile_gemm_read(C.byref(ms), C.byref(fl), C.byref(nl)))
         native.check(L.mtgv_profile_gemm_bytes(C.byref(by)))
-        groups = None
+        groups, fill_per_step = None, 0.0
         if rank == 0:
             import csv
             import tempfile
@@ -266,8 +269,9 @@ def main():
             recs = list(csv.DictReader(open(tmp_csv)))
             os.unlink(tmp_csv)
             groups = group_launches(recs, nprof, precision)
+            fill_per_step = sum(float(r.get("fill", 0) or 0) for r in recs) / nprof
         native.check(L.mtgv_profile_gemm(0))
-        prof = (ms.value / nprof, fl.value / nprof, int(nl.value // nprof), by.value / nprof, groups)
+        prof = (ms.value / nprof, fl.value / nprof, int(nl.value // nprof), by.value / nprof, groups, fill_per_step)
         barrier()
 
     if rank == 0:
@@ -275,7 +279,7 @@ def main():
         det_flops = detector.flops_per_frame()
         res["config"]["algorithmic_gflop_per_card"] = round((gflops_enc + dw_enc + det_flops / K + 2 * a.bank * 768) / 1e9, 3)
         if prof is not None:
-            gemm_ms, gemm_fl, launches, gemm_bytes, groups = prof
+            gemm_ms, gemm_fl, launches, gemm_bytes, groups, fill_bytes = prof
             sec = gemm_ms * 1e-3
             tfl = gemm_fl / sec / 1e12 if sec > 0 else 0.0
             gbs = gemm_bytes / sec / 1e9 if sec > 0 else 0.0
@@ -318,6 +322,11 @@ def main():
                 "min_ms_at_hbm_peak": round(t_hbm * 1e3, 3),
                 "mfma_view": mfma_view,
                 "hbm_view": hbm_view,
+                # The resource the tiling actually leans on: every tile pulls its A and B panels (4 B per element) through
+                # L2 into LDS.  Ceilings: gather-into-LDS rates measured on this part (MI355X_MICROARCH.md, "Indexed rows").
+                "lds_fill_view": {"gbyte_per_step": round(fill_bytes / 1e9, 2),
+                                  "achieved_tbs": round(fill_bytes / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
+                                  "ceiling_tbs": {"infinity_cache_resident": 8.6, "l2_resident": 17.8}, "unit": "TB/s"},
                 "measured": "HIP events around every launch on its stream, 2 single-stream passes after the timed region",
             }
         if world == 1 and not a.no_cpu_baseline:

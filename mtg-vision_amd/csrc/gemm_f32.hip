@@ -38,7 +38,7 @@ struct GemmProf {
   double flops = 0;
   double bytes = 0;  // compulsory HBM bytes: every operand element read once, every output written once
   long launches = 0;
-  struct Rec { int M, N, K, KH, stride, batch, act, apro, grn, topk, sp; double bytes; };
+  struct Rec { int M, N, K, KH, stride, batch, act, apro, grn, topk, sp; double bytes, fill; };
   std::vector<Rec> recs;
 } g_prof;
 }  // namespace
@@ -56,7 +56,7 @@ void gemm_profile_enable(bool on) {
 void gemm_profile_dump(const char* path) {
   FILE* f = fopen(path, "w");
   MTGV_CHECK(f != nullptr, ERR_RUNTIME, "cannot open %s", path);
-  fprintf(f, "idx,M,N,K,KH,stride,batch,act,apro,grn,topk,tm,tn,bk,ms,tflops,bytes,sp\n");
+  fprintf(f, "idx,M,N,K,KH,stride,batch,act,apro,grn,topk,tm,tn,bk,ms,tflops,bytes,sp,fill\n");
   for (size_t i = 0; i + 1 < g_prof.used && i / 2 < g_prof.recs.size(); i += 2) {
     HIP_OK(hipEventSynchronize(g_prof.ev[i + 1]));
     float t = 0.f;
@@ -64,8 +64,8 @@ void gemm_profile_dump(const char* path) {
     const auto& r = g_prof.recs[i / 2];
     const GemmPlan pl = r.topk ? GemmPlan{1, 2, 16, 0, 0} : gemm_plan(r.M, r.N, r.K, r.act != 0, r.apro != 0);
     const double fl = 2.0 * r.M * r.N * r.K * r.batch;
-    fprintf(f, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f,%.0f,%d\n", i / 2, r.M, r.N, r.K, r.KH, r.stride, r.batch, r.act,
-            r.apro, r.grn, r.topk, pl.tm, pl.tn, pl.bk, t, fl / (t * 1e-3) / 1e12, r.bytes, r.sp);
+    fprintf(f, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f,%.0f,%d,%.0f\n", i / 2, r.M, r.N, r.K, r.KH, r.stride, r.batch, r.act,
+            r.apro, r.grn, r.topk, pl.tm, pl.tn, pl.bk, t, fl / (t * 1e-3) / 1e12, r.bytes, r.sp, r.fill);
   }
   fclose(f);
   gemm_sp_stamps_dump((std::string(path) + ".stamps").c_str());
@@ -87,7 +87,8 @@ void gemm_profile_read(double* ms, double* flops, long* launches) {
   if (launches) *launches = g_prof.launches;
 }
 
-static void prof_begin(const GemmArgs& a, hipStream_t s, int sp = 0) {
+// fill: bytes the launch's tiles pull into LDS (every tile its A and B panels; 4 bytes per element in either format)
+static void prof_begin(const GemmArgs& a, hipStream_t s, int sp, double fill) {
   if (!g_prof.on) return;
   while (g_prof.ev.size() < g_prof.used + 2) {
     hipEvent_t e;
@@ -105,7 +106,7 @@ static void prof_begin(const GemmArgs& a, hipStream_t s, int sp = 0) {
     const double by = 4.0 * ((a.strideA != 0 || a.batch == 1 ? a.batch : 1) * a_el + (a.strideW != 0 || a.batch == 1 ? a.batch : 1) * w_el +
                              a.batch * (o_el + r_el));
     g_prof.bytes += by;
-    g_prof.recs.push_back({a.M, a.N, a.K, a.KH, a.stride, a.batch, a.act, a.a_scale != nullptr, a.grn_part != nullptr, a.topk, sp, by});
+    g_prof.recs.push_back({a.M, a.N, a.K, a.KH, a.stride, a.batch, a.act, a.a_scale != nullptr, a.grn_part != nullptr, a.topk, sp, by, fill});
   }
   g_prof.launches += 1;
 }
@@ -333,7 +334,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
     const SpPlan sp = gemm_sp_plan(a);  // the LDS-DMA split kernel takes every launch it can run
     if (sp.cfg >= 0) {
       if (a.grn_part) MTGV_CHECK(a.hw > 0 && a.M % a.hw == 0, ERR_INVALID, "gemm: hw=%d must divide M=%d", a.hw, a.M);
-      prof_begin(a, s, 1);
+      prof_begin(a, s, 1, g_prof.on ? gemm_sp_fill_bytes(a, sp) : 0.0);
       gemm_sp_launch(a, sp, s);
       prof_end(s);
       return;
@@ -368,7 +369,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
     MTGV_CHECK(pl.tm == 1 && pl.tn == 2 && pl.bk == 16 && !conv && !apro, ERR_INVALID, "gemm: top-k epilogue needs the 128x64x16 tile");
     MTGV_CHECK(a.cand_s != nullptr && a.cand_i != nullptr && a.topk <= 128, ERR_INVALID, "gemm: bad top-k arguments");
   }
-  prof_begin(a, s);
+  prof_begin(a, s, 0, (double)grid * a.batch * (pl.bm() + pl.bn()) * a.K * 4.0);
   const bool found = gemm_precision() == GEMM_PREC_F16X3 ? gemm_dispatch_f16x3(g, pl, conv, apro, grid, s)
                                                          : gemm_dispatch_f32(g, pl, conv, apro, grid, s);
   if (found) {
