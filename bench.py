@@ -236,9 +236,11 @@ def main():
             "bank_layout": ("row-sharded %d-way + RCCL all-gather of per-shard top-1" % world) if sharded else "replicated",
             "weights": "random-init (seeded), no trained weights offline",
             "gemm_precision_mode": precision,
-            "gemm_operands": "f32 operands, f32-input MFMA" if precision == "f32" else "f32 tensors in HBM; GEMM operands split on the fly "
-            "into fp16 hi+lo, 3 fp16 MFMAs per product, f32 accumulate (error vs fp64 at the f32 level, tests/test_gpu_precision.py)",
-            "streams": "2 (detect of step i+1 beside embed+match of step i)" if overlap else "1",
+            "gemm_operands": "f32 operands, f32-input MFMA" if precision == "f32" else "f32-grade values kept as fp16 hi+lo pairs (4 B per "
+            "element: weights and bank with a power-of-two scale per row, GEMM-bound activations written that way by their producers, the "
+            "rest split when a fragment is read), 3 fp16 MFMAs per product, f32 accumulate (error vs fp64 at the f32 level, "
+            "tests/test_gpu_precision.py)",
+            "streams": "2 (detect of step i+1 beside embed+match of step i; MTGV_OVERLAP=on set by bench.py, the library default is 1)" if overlap else "1",
         },
     }
 
