@@ -10,21 +10,29 @@
 //   A, AMODE 2 (CONV)    SP8 NHWC activations gathered by the DMA's per-lane source address (implicit GEMM, no
 //                        im2col): m -> (img, oh, ow), k -> (kh, kw, c); taps outside the image and the K tail read a
 //                        zero page.  Cin % 8 == 0 keeps every 8-channel chunk inside one tap.
+//   A, AMODE 5 (WINDOW)  3x3 / stride 1 / pad 1 convs with Cin % 32 == 0: per 32-channel slice the tile's input window
+//                        (BM + 2 W + 2 pixels x 128 B) is filled once and the nine taps read shifted fragments out of it,
+//                        zeroed by predicate where the tap leaves the image; only the taps' weight stages ring.
+//                        Accumulation order: channel slice outer, tap inner.
+//   A, AMODE 3 / 4       f32 rows by LDS-DMA; the wave that feeds a fragment to the MFMAs multiplies it by the per-image
+//                        multipliers (AMODE 3: GRN apply, convnextv2.py:171-174; one extra 1 KB DMA piece per stage holds
+//                        [8 images][32 k]) and splits it into hi / lo on the spot.
 //   A, AMODE 1 (REG)     f32 rows: global -> VGPR (issued before the stage's MFMAs) -> optional per-image multiplier
-//                        (GRN apply, convnextv2.py:171-174) -> split -> ds_write_b128 (after the MFMAs).
+//                        -> split -> ds_write_b128 (after the MFMAs).  Fallback of 3 / 4: unaligned rows, range-guarded
+//                        inputs (a_mul != 1), tiles spanning more than 8 images.
 // LDS image of a stage: [row][SPR slots of 16 B], slot' = slot ^ sw(row), sw = (row>>1)&7 for 128-byte rows,
 // (row>>2)&3 for 64-byte rows: every ds_read_b128 lane group covers all 64 banks once.  The DMA destination is
 // lane-linear, so the swizzle is applied to the per-lane source address (and to the ds_write address in REG mode).
 //
 // MFMA orientation: weights are the first operand, so the accumulator has n on registers and m on lanes - a lane owns
-// one output row and 4 consecutive columns per register group.  The epilogue applies wscale, bias and the activation
-// in registers and stages each 32-row slab through LDS, so that global stores and residual loads are whole 128-byte
-// lines; in the read-back a lane keeps the same 4 columns, which makes the GRN sum(x^2) partials lane-local.
-// SP8 output (out_fmt 1): the two lanes that own the halves of an 8-column chunk trade halves (v_permlane32_swap), so
-// one holds the chunk's hi piece and the other its lo piece - the same 16-byte slots the f32 path stages.
+// one output row and 4 consecutive columns per register group.  Epilogue: the accumulators of a 32-row slab are staged
+// raw through LDS and read back 8 lanes per 128-byte row segment; a lane keeps the same 4 columns of every column block,
+// so wscale, bias and the GRN sum(x^2) partials are lane-local registers, and scale / bias / activation / residual / SP8
+// packing (v_cvt_pk_f16_f32 + a DPP exchange between the two lanes of an 8-column chunk) all happen on the read-back
+// side, followed by whole-line stores.  EPI >= 0 fixes the epilogue's shape at compile time.
 //
-// Products: lo*hi + hi*lo + hi*hi per k16 step into the same accumulator, k ascending: results do not depend on the
-// tile configuration.
+// Products: lo*hi + hi*lo + hi*hi per k16 step into the same accumulator, k ascending (WINDOW: slice-major): results
+// do not depend on the tile configuration.
 #pragma once
 #include <type_traits>
 
