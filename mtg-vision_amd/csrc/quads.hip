@@ -150,32 +150,77 @@ __global__ __launch_bounds__(QT) void mask_quads_kernel(const void* __restrict__
   }
   __syncthreads();
 
-  // ---- 2. hull (thread 0) ----
-  if (tid == 0) {
-    int np = 0;
-    for (int y = 0; y < H; ++y) {
-      if (cnt[y] == 0) continue;
-      pts[np++] = P2{xmin[y], y};
-      if (xmax[y] != xmin[y]) pts[np++] = P2{xmax[y], y};
+  // ---- 2. hull ----
+  // 2a. the row extents in row order (xmin, then xmax when it differs): block-wide prefix sum instead of a serial pass
+  {
+    const int R = (H + QT - 1) / QT;  // consecutive rows per thread
+    const int y_begin = tid * R;
+    int c_local = 0;
+    for (int k = 0; k < R; ++k) {
+      const int y = y_begin + k;
+      if (y < H && cnt[y] > 0) c_local += xmax[y] != xmin[y] ? 2 : 1;
     }
-    int h = 0;
+    int incl = c_local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      if ((tid & 63) >= d) incl += v;
+    }
+    if ((tid & 63) == 63) s_edge[tid >> 6] = incl;  // s_edge is free until the contraction
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += s_edge[w];
+    int pos = base + incl - c_local;
+    for (int k = 0; k < R; ++k) {
+      const int y = y_begin + k;
+      if (y < H && cnt[y] > 0) {
+        pts[pos++] = P2{xmin[y], y};
+        if (xmax[y] != xmin[y]) pts[pos++] = P2{xmax[y], y};
+      }
+    }
+    if (tid == QT - 1) s_cnt = base + incl;
+    __syncthreads();
+  }
+  // 2b. monotone chain: the two passes run side by side on two waves; the top two points of a chain stay in
+  // registers (only a pop reads LDS) and the next point is fetched one step ahead
+  {
+    const int np = s_cnt;
+    auto chain = [&](P2* out, bool fwd) -> int {
+      int n = 0;
+      P2 a{0, 0}, b{0, 0};
+      int i = fwd ? 0 : np - 1;
+      const int step = fwd ? 1 : -1;
+      P2 nextp = pts[i];
+      for (int k = 0; k < np; ++k) {
+        const P2 p = nextp;
+        i += step;
+        if (k + 1 < np) nextp = pts[i];
+        while (n >= 2 && cross3(a, b, p) <= 0) {
+          --n;
+          b = a;
+          if (n >= 2) a = out[n - 2];
+        }
+        out[n++] = p;
+        a = b, b = p;
+      }
+      return n;
+    };
+    if (np >= 2) {
+      if (tid == 0) s_h = chain(lower, true);       // nl
+      if (tid == 64) s_pick = chain(upper, false);  // nu
+    }
+    __syncthreads();
     if (np <= 1) {
-      for (int i = 0; i < np; ++i) lower[i] = pts[i];
-      h = np;
+      if (tid == 0) {
+        for (int i = 0; i < np; ++i) lower[i] = pts[i];
+        s_h = np;
+      }
     } else {
-      int nl = 0, nu = 0;
-      for (int i = 0; i < np; ++i) {
-        while (nl >= 2 && cross3(lower[nl - 2], lower[nl - 1], pts[i]) <= 0) --nl;
-        lower[nl++] = pts[i];
-      }
-      for (int i = np - 1; i >= 0; --i) {
-        while (nu >= 2 && cross3(upper[nu - 2], upper[nu - 1], pts[i]) <= 0) --nu;
-        upper[nu++] = pts[i];
-      }
-      h = nl - 1;
-      for (int i = 0; i < nu - 1; ++i) lower[h++] = upper[i];
+      const int nl = s_h, nu = s_pick;
+      __syncthreads();
+      for (int i = tid; i < nu - 1; i += QT) lower[nl - 1 + i] = upper[i];
+      if (tid == 0) s_h = nl - 1 + nu - 1;
     }
-    s_h = h;
   }
   __syncthreads();
   const int h = s_h;
@@ -214,14 +259,19 @@ __global__ __launch_bounds__(QT) void mask_quads_kernel(const void* __restrict__
     const double ux = bx - px, uy = by - py, wx = cx - px, wy = cy - py;
     return 0.5 * fabs(ux * wy - uy * wx);
   };
+  // the contraction point of every candidate edge is kept beside its area (pts / upper are free after the hull), so
+  // a pick costs no recomputation, and the four candidates it invalidates are recomputed by four lanes at once
+  double* const apx = reinterpret_cast<double*>(pts);
+  double* const apy = reinterpret_cast<double*>(upper);
   if (h >= 4) {
     for (int i = tid; i < h; i += QT) {
       double px, py;
       ar[i] = contract(i, px, py);
+      apx[i] = px, apy[i] = py;
     }
     __syncthreads();
     int cnt_v = h;
-    while (cnt_v > 4) {  // cnt_v is block-uniform: every thread sees the same s_pick
+    while (cnt_v > 4) {  // cnt_v is block-uniform: every thread computes the same pick
       double best = INFINITY;
       int bi = 0x7fffffff;
       for (int i = tid; i < h; i += QT)
@@ -234,52 +284,81 @@ __global__ __launch_bounds__(QT) void mask_quads_kernel(const void* __restrict__
       }
       if ((tid & 63) == 0) s_area[tid >> 6] = best, s_edge[tid >> 6] = bi;
       __syncthreads();
-      if (tid == 0) {
-        double gb = INFINITY;
-        int gi = 0x7fffffff;
-        for (int w = 0; w < QT / 64; ++w)
-          if (s_area[w] < gb || (s_area[w] == gb && s_edge[w] < gi)) gb = s_area[w], gi = s_edge[w];
-        if (!(gb < INFINITY)) {
-          s_pick = -1;
-        } else {
-          double px, py;
-          (void)contract(gi, px, py);
+      double gb = INFINITY;
+      int gi = 0x7fffffff;
+      for (int w = 0; w < QT / 64; ++w)
+        if (s_area[w] < gb || (s_area[w] == gb && s_edge[w] < gi)) gb = s_area[w], gi = s_edge[w];
+      if (!(gb < INFINITY)) break;  // nothing left to contract (block-uniform)
+      if (tid < 64) {  // one wave: LDS operations of a wave execute in order
+        if (tid == 0) {
           const int c = nxt[gi];
-          vx[gi] = px, vy[gi] = py;
+          vx[gi] = apx[gi], vy[gi] = apy[gi];
           alive[c] = 0;
           nxt[gi] = nxt[c];
           prv[nxt[c]] = gi;
-          const int js[4] = {prv[prv[gi]], prv[gi], gi, nxt[gi]};
-          for (int k = 0; k < 4; ++k) {
-            double qx, qy;
-            ar[js[k]] = contract(js[k], qx, qy);
-          }
-          s_pick = gi;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tid < 4) {
+          const int p1 = prv[gi];
+          const int j = tid == 0 ? prv[p1] : tid == 1 ? p1 : tid == 2 ? gi : nxt[gi];
+          double qx, qy;
+          const double a = contract(j, qx, qy);
+          // the four slots may coincide on tiny polygons; equal slots compute equal values
+          ar[j] = a, apx[j] = qx, apy[j] = qy;
         }
       }
       __syncthreads();
-      if (s_pick < 0) break;
       cnt_v -= 1;
     }
     if (tid == 0) s_cnt = cnt_v;
   } else if (tid == 0) {
     s_cnt = h;
   }
+  // ---- 4. corners, orientation ----
+  // integer sums / extrema over the rows by the whole block (order-free), the floating-point rest by thread 0
+  __shared__ long long s_red[QT / 64][3];
+  __shared__ int s_ext[QT / 64][4];
+  {
+    long long r_n = 0, r_sx = 0, r_sy = 0;
+    int r_ymin = 0x7fffffff, r_ymax = -1, r_xlo = 0x7fffffff, r_xhi = -1;
+    for (int y = tid; y < H; y += QT) {
+      const int c = cnt[y];
+      if (c == 0) continue;
+      r_n += c;
+      r_sx += sumx[y];
+      r_sy += (long long)y * c;
+      r_ymin = y < r_ymin ? y : r_ymin;
+      r_ymax = y > r_ymax ? y : r_ymax;
+      r_xlo = xmin[y] < r_xlo ? xmin[y] : r_xlo;
+      r_xhi = xmax[y] > r_xhi ? xmax[y] : r_xhi;
+    }
+#pragma unroll
+    for (int mask = 32; mask > 0; mask >>= 1) {
+      r_n += __shfl_xor(r_n, mask);
+      r_sx += __shfl_xor(r_sx, mask);
+      r_sy += __shfl_xor(r_sy, mask);
+      const int a0 = __shfl_xor(r_ymin, mask), a1 = __shfl_xor(r_ymax, mask), a2 = __shfl_xor(r_xlo, mask), a3 = __shfl_xor(r_xhi, mask);
+      r_ymin = a0 < r_ymin ? a0 : r_ymin;
+      r_ymax = a1 > r_ymax ? a1 : r_ymax;
+      r_xlo = a2 < r_xlo ? a2 : r_xlo;
+      r_xhi = a3 > r_xhi ? a3 : r_xhi;
+    }
+    if ((tid & 63) == 0) {
+      s_red[tid >> 6][0] = r_n, s_red[tid >> 6][1] = r_sx, s_red[tid >> 6][2] = r_sy;
+      s_ext[tid >> 6][0] = r_ymin, s_ext[tid >> 6][1] = r_ymax, s_ext[tid >> 6][2] = r_xlo, s_ext[tid >> 6][3] = r_xhi;
+    }
+  }
   __syncthreads();
   if (tid != 0) return;
 
-  // ---- 4. corners, orientation (thread 0) ----
   long long ntot = 0, sx_tot = 0, sy_tot = 0;
-  int ymin = -1, ymax = -1, xlo = 0x7fffffff, xhi = -1;
-  for (int y = 0; y < H; ++y) {
-    if (cnt[y] == 0) continue;
-    ntot += cnt[y];
-    sx_tot += sumx[y];
-    sy_tot += (long long)y * cnt[y];
-    if (ymin < 0) ymin = y;
-    ymax = y;
-    xlo = xmin[y] < xlo ? xmin[y] : xlo;
-    xhi = xmax[y] > xhi ? xmax[y] : xhi;
+  int ymin = 0x7fffffff, ymax = -1, xlo = 0x7fffffff, xhi = -1;
+  for (int w = 0; w < QT / 64; ++w) {
+    ntot += s_red[w][0], sx_tot += s_red[w][1], sy_tot += s_red[w][2];
+    ymin = s_ext[w][0] < ymin ? s_ext[w][0] : ymin;
+    ymax = s_ext[w][1] > ymax ? s_ext[w][1] : ymax;
+    xlo = s_ext[w][2] < xlo ? s_ext[w][2] : xlo;
+    xhi = s_ext[w][3] > xhi ? s_ext[w][3] : xhi;
   }
   float* q = quads + (size_t)n * 8;
   if (ntot == 0) {
