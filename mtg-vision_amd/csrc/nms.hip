@@ -5,8 +5,9 @@
 //   1. candidates: max class score > conf; key = score bits << 32 | ~anchor  (u64)
 //   2. bitonic sort of the keys in LDS, descending -> score desc, anchor asc (deterministic)
 //   3. sorted boxes -> xyxy + class offset, areas (workspace in HBM, L2-resident)
-//   4. greedy sweep: for every surviving box, each wave tests 64 later boxes per step and
-//      publishes the result with one __ballot into the suppression bitmask (no atomics)
+//   4. greedy sweep, 64 sorted boxes at a time: one wave resolves the word in order (readlane broadcast + __ballot),
+//      then all waves apply the word's kept boxes to the later words, one __ballot per word into the suppression
+//      bitmask (no atomics)
 //
 // All box arithmetic uses explicitly rounded single operations (no FMA contraction), so the
 // kept indices are bit-identical to the float32 CPU oracle (oracle/detector_ref.py nms_single).
@@ -101,39 +102,65 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
   }
   __syncthreads();  // global writes by this block are visible to it after the barrier
 
-  // 4. greedy sweep; the key buffer is reused as the suppression bitmask (64 boxes per word)
+  // 4. greedy sweep, one 64-box word of the sorted list at a time; the key buffer is reused as the suppression bitmask.
+  //    (a) wave 0 resolves the word in order: the lowest surviving lane is kept (v_readlane broadcasts its box) and
+  //        knocks out the later lanes it overlaps, published with one __ballot per keep - no block barrier;
+  //    (b) every wave then applies the word's kept boxes (parked in LDS) to its share of the later words.
+  //    Same keep list as the box-at-a-time sweep: a box is kept iff no earlier kept box overlaps it beyond the
+  //    threshold; two block barriers per word instead of two per kept box.
   unsigned long long* supp = keys;
+  __shared__ float kbox[64 * 5];  // x1 y1 x2 y2 area of the word being resolved
+  __shared__ unsigned long long s_kmask;
   const int nwords = (count + 63) >> 6;
   for (int i = tid; i < nwords; i += NMS_THREADS) supp[i] = 0ull;
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6, nwaves = NMS_THREADS >> 6;
-  int i = 0;
-  while (true) {
-    while (i < count && ((supp[i >> 6] >> (i & 63)) & 1ull)) ++i;  // same scan in every thread
-    if (i >= count) break;
-    if (tid == 0) s_keep[s_nkeep] = i;
-    const int nk = s_nkeep + 1;  // read before the barrier below, written after it
-    __syncthreads();
-    if (tid == 0) s_nkeep = nk;
-    if (nk >= max_det) {
-      __syncthreads();
-      break;
-    }
-    const float ax1 = obox[(long)i * 4], ay1 = obox[(long)i * 4 + 1], ax2 = obox[(long)i * 4 + 2], ay2 = obox[(long)i * 4 + 3];
-    const float aarea = area[i];
-    for (int wd = (i >> 6) + wave; wd < nwords; wd += nwaves) {
-      const int j = (wd << 6) + lane;
-      bool s = false;
-      if (j > i && j < count) {
-        const float iou = box_iou_rn(ax1, ay1, ax2, ay2, aarea, obox[(long)j * 4], obox[(long)j * 4 + 1], obox[(long)j * 4 + 2],
-                                     obox[(long)j * 4 + 3], area[j]);
-        s = iou > iou_thres;
+  for (int w0 = 0; w0 < nwords; ++w0) {
+    if (wave == 0) {
+      const int j = (w0 << 6) + lane;
+      const bool valid = j < count;
+      const float bx1 = valid ? obox[(long)j * 4] : 0.f, by1 = valid ? obox[(long)j * 4 + 1] : 0.f;
+      const float bx2 = valid ? obox[(long)j * 4 + 2] : 0.f, by2 = valid ? obox[(long)j * 4 + 3] : 0.f;
+      const float barea = valid ? area[j] : 0.f;
+      kbox[lane * 5 + 0] = bx1, kbox[lane * 5 + 1] = by1, kbox[lane * 5 + 2] = bx2, kbox[lane * 5 + 3] = by2, kbox[lane * 5 + 4] = barea;
+      unsigned long long alive = __ballot(valid) & ~supp[w0];
+      unsigned long long kept = 0ull;
+      int nk = s_nkeep;
+      while (alive != 0ull && nk < max_det) {
+        const int k = __builtin_ctzll(alive);  // wave-uniform: the earliest surviving box of the word
+        if (lane == 0) s_keep[nk] = (w0 << 6) + k;
+        nk += 1;
+        kept |= 1ull << k;
+        alive &= ~(1ull << k);
+        if (nk >= max_det) break;
+        const float ax1 = __shfl(bx1, k), ay1 = __shfl(by1, k), ax2 = __shfl(bx2, k), ay2 = __shfl(by2, k), aarea = __shfl(barea, k);
+        const bool s = lane > k && ((alive >> lane) & 1ull) && box_iou_rn(ax1, ay1, ax2, ay2, aarea, bx1, by1, bx2, by2, barea) > iou_thres;
+        alive &= ~__ballot(s);
       }
-      const unsigned long long m = __ballot(s);
-      if (lane == 0 && m) supp[wd] |= m;  // one writer per word per step
+      if (lane == 0) s_nkeep = nk, s_kmask = kept;
     }
-    ++i;
     __syncthreads();
+    const unsigned long long kept = s_kmask;
+    if (s_nkeep >= max_det) break;  // block-uniform
+    if (kept != 0ull) {
+      for (int wd = w0 + 1 + wave; wd < nwords; wd += nwaves) {
+        const int j = (wd << 6) + lane;
+        bool s = false;
+        if (j < count) {
+          const float bx1 = obox[(long)j * 4], by1 = obox[(long)j * 4 + 1], bx2 = obox[(long)j * 4 + 2], by2 = obox[(long)j * 4 + 3];
+          const float barea = area[j];
+          unsigned long long m = kept;
+          while (m != 0ull && !s) {  // any kept box of the word suffices; the order of the tests does not matter
+            const int k = __builtin_ctzll(m);
+            m &= m - 1;
+            s = box_iou_rn(kbox[k * 5], kbox[k * 5 + 1], kbox[k * 5 + 2], kbox[k * 5 + 3], kbox[k * 5 + 4], bx1, by1, bx2, by2, barea) > iou_thres;
+          }
+        }
+        const unsigned long long mk = __ballot(s);
+        if (lane == 0 && mk) supp[wd] |= mk;  // one writer per word per step
+      }
+    }
+    __syncthreads();  // supp of the next word is complete; kbox and s_kmask may be rewritten
   }
   __syncthreads();
 
