@@ -395,9 +395,16 @@ __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restri
   float local = 0.f;
   for (int n = tid; n < N; n += 256) {
     float sum = 0.f;
-    for (int t = t_first; t <= t_last; ++t) {
-      const int seg = img - (int)fdiv((uint32_t)(t * bm), d_hw);
-      sum += part[((long)t * segmax + seg) * N + n];
+    for (int t0 = t_first; t0 <= t_last; t0 += 8) {  // 8 loads in flight, added in unit order (same sum as one by one)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u;
+        const int seg = img - (int)fdiv((uint32_t)(t * bm), d_hw);
+        v[u] = t <= t_last ? part[((long)t * segmax + seg) * N + n] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
     }
     const float gval = sqrtf(sum);
     gx[n] = gval;
