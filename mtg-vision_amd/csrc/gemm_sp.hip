@@ -191,6 +191,11 @@ bool window_conv_fits(const GemmArgs& a, const SpPlan& pl) {
   return lds <= 80 * 1024;
 }
 
+bool topk_sp_on() {
+  static const bool on = [] { const char* e = getenv("MTGV_SP_TOPK"); return e == nullptr || atoi(e) != 0; }();
+  return on;
+}
+
 bool gemm_sp_active() { return sp_enabled() && gemm_precision() == GEMM_PREC_F16X3; }
 
 bool gemm_sp_takes_sp8(const float* W, int M, int N, int K, int lda, int c_off) {
@@ -210,7 +215,20 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
   if (!sp_enabled() || gemm_precision() != GEMM_PREC_F16X3) return none();
   const bool conv = is_conv(a);
   const bool remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
-  if (a.batch != 1 || a.topk > 0 || a.crop_boxes != nullptr || a.m_count != nullptr) return none();
+  if (a.batch != 1 || a.crop_boxes != nullptr || a.m_count != nullptr) return none();
+  if (a.topk > 0) {  // match path: 128 x 192 tiles, f32 queries by DMA (A mode 4), fused top-k (gemm_sp_kernel.h, EPI 16)
+    if (sp8_in || conv || a.K % 8 != 0 || a.c_total % 8 != 0 || a.c_off % 8 != 0 || ((uintptr_t)a.A & 15) != 0 || a.a_scale != nullptr ||
+        a.a_mul != 1.0f || a.res != nullptr || a.act != ACT_NONE || a.M < 128 || a.N < 192 || !sp8_lookup(a.W, a.K, nullptr, nullptr) ||
+        !topk_sp_on())
+      return none();
+    const SpCfg& k1 = kCfg[1];
+    pl.cfg = 1;
+    pl.bm = k1.bm(), pl.bn = k1.bn();
+    pl.unit_rows = 32 * k1.tm;
+    pl.tiles_m = ceil_div(a.M, k1.bm());
+    pl.tiles_n = ceil_div(a.N, k1.bn());
+    return pl;
+  }
   if (conv && (!sp8_in || a.stride_w > 0 || a.Cin % 8 != 0)) return none();  // the gather is a DMA-path feature
   if (remap && !sp8_in) return none();
   if (a.K % 8 != 0 || a.c_total % 8 != 0 || a.c_off % 8 != 0 || a.ldo % 4 != 0 || a.o_off % 4 != 0 ||
@@ -263,6 +281,16 @@ bool stamps_on() {
   return on;
 }
 }  // namespace
+
+// top-k candidate layout of a launch the SP kernel would take: groups of `cols` columns, `slots` groups per row
+bool gemm_sp_topk_layout(const GemmArgs& a, int* slots, int* cols) {
+  const SpPlan pl = gemm_sp_plan(a);
+  if (pl.cfg < 0) return false;
+  const SpCfg& k = kCfg[pl.cfg];
+  *slots = pl.tiles_n * k.wn;
+  *cols = 32 * k.tn;
+  return true;
+}
 
 double gemm_sp_fill_bytes(const GemmArgs& a, const SpPlan& pl) {
   const SpCfg& k = kCfg[pl.cfg];
@@ -322,6 +350,7 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   g.a_unmul = a.a_fmt == 1 ? 1.0f : a.a_unmul;
   g.zero = zero_page();
   g.tiles_m = pl.tiles_m, g.tiles_n = pl.tiles_n;
+  g.cand_s = a.cand_s, g.cand_i = a.cand_i, g.topk = a.topk;
   g.act = a.act;
   g.H = a.H, g.Wd = a.Wd, g.Cin = a.Cin, g.KW = a.KW, g.stride = a.stride, g.pad = a.pad, g.OH = a.OH, g.OW = a.OW;
   g.d_ohw = make_fastdiv((uint32_t)(a.OH * a.OW));

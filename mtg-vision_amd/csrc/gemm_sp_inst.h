@@ -56,6 +56,15 @@ void sp_pick(const SpDev& g, int epi, hipStream_t s) {
 // Specialised epilogues: 0 f32 out; 1 SP8 out; 1|4 SP8 out + SP8 residual (detector); 2 f32 out + f32 residual
 // (pwconv2); 8 f32 out + GRN sums (pwconv1).
 void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_t s) {
+  if (g.topk > 0) {  // match path: f32 queries by DMA, fused top-k epilogue; only the 128 x 192 configuration carries it
+#if SP_CFG_ID == 1
+    MTGV_CHECK(amode == 4 && g.act == ACT_NONE, ERR_INVALID, "gemm_sp: top-k needs aligned f32 queries");
+    sp_launch_one<4, ACT_NONE, 16>(g, s);
+    return;
+#else
+    MTGV_CHECK(false, ERR_INVALID, "gemm_sp: no top-k instance in this configuration");
+#endif
+  }
   const int epi = sp_epi_of(g);
   if (amode == 0) {
     switch (g.act) {

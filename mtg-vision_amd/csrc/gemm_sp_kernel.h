@@ -45,6 +45,9 @@ namespace mtgv {
 typedef float spf16 __attribute__((ext_vector_type(16)));
 
 struct SpDev {
+  float* cand_s = nullptr;      // EPI 16 (top-k): per (row, column tile, wave column) the k best (score, column) pairs
+  int* cand_i = nullptr;
+  int topk = 0;
   long* stamps = nullptr;       // tuning aid (MTGV_SP_STAMPS): [tile][8] s_memtime at entry / first stage in / loop end / exit
   const char* A = nullptr;      // AMODE 0/2: SP8 bytes; AMODE 1: f32
   long a_rowb = 0;              // bytes per A row (pixel)
@@ -511,6 +514,57 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   __builtin_amdgcn_s_barrier();  // every wave is done with the ring: it becomes the store staging area
   const long st2 = g.stamps != nullptr ? (long)__builtin_amdgcn_s_memtime() : 0;
   if (!wave_active) return;
+
+  if constexpr (EPI == 16) {
+    // ---- fused top-k (match path): the scores never leave registers.  A lane holds 16 TN columns of its row, its
+    // partner lane ^ 32 the other 16 TN; each round picks the (score desc, column asc) maximum of the wave's 32 TN
+    // columns and retires it.  Candidates: cand[m][(tile_n * WN + wn) * topk + kk]; topk_merge_kernel finishes.
+    const int ncol0 = n0 + wn * TN * 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = ncol0 + j * 32 + gq * 8 + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool nok = n + e < g.N;
+          const float ws = (g.wscale != nullptr && nok) ? g.wscale[n + e] * g.a_unmul : g.a_unmul;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[i][j][4 * gq + e] = nok ? acc[i][j][4 * gq + e] * ws : -INFINITY;
+        }
+      }
+    const long slots = (long)g.tiles_n * WN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * TM * 32 + i * 32 + r;
+      for (int kk = 0; kk < g.topk; ++kk) {
+        float bs = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {  // ascending column order inside the lane: the first maximum has the lowest column
+            const float v = acc[i][j][q];
+            const int n = ncol0 + j * 32 + (q >> 2) * 8 + 4 * h + (q & 3);
+            if (v > bs || (v == bs && n < bi)) bs = v, bi = n;
+          }
+        const float os = __shfl_xor(bs, 32);
+        const int oi = __shfl_xor(bi, 32);
+        if (os > bs || (os == bs && oi < bi)) bs = os, bi = oi;
+        if (h == 0 && m < g.M) {
+          const long o = ((long)m * slots + (long)tile_n * WN + wn) * g.topk + kk;
+          g.cand_s[o] = bs;
+          g.cand_i[o] = (bs == -INFINITY) ? -1 : bi;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (ncol0 + j * 32 + (q >> 2) * 8 + 4 * h + (q & 3) == bi) acc[i][j][q] = -INFINITY;
+      }
+    }
+    return;
+  }
 
   // The accumulators of one 32-row slab go to LDS untouched (register group gq of column block j holds columns
   // 32 j + 8 gq + 4 h + 0..3 of row lane & 31) and are read back row-wise, 8 lanes per 128-byte row segment: a lane

@@ -4,6 +4,7 @@
 //   2. gemm_f32 (EPI=1)          S tile = Q B^T on f32 MFMA, per-tile top-k in registers
 //   3. topk_merge_kernel         tiles_n*k candidates per query -> top k (score desc, id asc)
 #include "match.h"
+#include "gemm_sp.h"
 #include "rowops.h"
 
 namespace mtgv {
@@ -100,13 +101,17 @@ void Bank::topk(const float* q, int b, int k, int64_t id_base, int64_t* ids, flo
   pl.tm = 1, pl.tn = 2, pl.bk = 16;
   pl.tiles_m = ceil_div(b, pl.bm());
   pl.tiles_n = ceil_div((int)size_, pl.bn());
-  const int kt = k < pl.bn() ? k : pl.bn();  // a 64-column tile cannot contribute more than 64 candidates
-  const size_t ncand = (size_t)pl.tiles_n * kt;
   qn_.ensure((size_t)b * dim_);
+  GemmArgs g = linear_args(qn_.p, dim_, vecs_.p, nullptr, nullptr, 0, b, (int)size_, dim_, ACT_NONE);
+  // candidate groups: 64-column tiles of the convert-on-load kernel, or the per-wave column ranges of the LDS-DMA kernel
+  int slots = pl.tiles_n, cols = pl.bn();
+  g.topk = 1;
+  (void)gemm_sp_topk_layout(g, &slots, &cols);
+  const int kt = k < cols ? k : cols;  // a group cannot contribute more candidates than it has columns
+  const size_t ncand = (size_t)slots * kt;
   cand_s_.ensure((size_t)b * ncand);
   cand_i_.ensure((size_t)b * ncand);
   l2norm_rows_launch(q, qn_.p, b, dim_, s);
-  GemmArgs g = linear_args(qn_.p, dim_, vecs_.p, nullptr, nullptr, 0, b, (int)size_, dim_, ACT_NONE);
   g.cand_s = cand_s_.p;
   g.cand_i = reinterpret_cast<int*>(cand_i_.p);
   g.topk = kt;
