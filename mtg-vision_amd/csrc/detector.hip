@@ -675,6 +675,42 @@ void Detector::proto(const std::string& H, const View& p3, int n, hipStream_t s)
   conv(cw_.at(H + ".proto.cv3"), view("pr3"), view("protos"), 1, ACT_SILU, nullptr, n, s);
 }
 
+// Mask logits of a few detections per frame (process_mask + crop_mask behind od_export.py:152): out[z][m][px] =
+// <coef[z][m], protos[z][px]> inside box m, 0 outside - f32 FMA chain in k order.  One thread per prototype pixel reads
+// its 32 channels once (128 contiguous bytes) and serves all the frame's kept rows; coefficients and scaled boxes sit in
+// LDS.  Rows beyond n_det[z] are left untouched, as the batched GEMM it replaces for small row counts did.
+__global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restrict__ coef, const float* __restrict__ protos,
+                                                         const int* __restrict__ n_det, const float* __restrict__ boxes,
+                                                         float* __restrict__ out, int npx, int pw, int mask_rows, int max_det,
+                                                         float crop_scale) {
+  __shared__ __attribute__((aligned(16))) float sc[16 * 32];
+  __shared__ float sb[16 * 4];
+  const int z = blockIdx.y;
+  const int mc = n_det[z] < mask_rows ? n_det[z] : mask_rows;
+  for (int i = threadIdx.x; i < mc * 32; i += 256) sc[i] = coef[(long)z * max_det * 32 + i];
+  if (threadIdx.x < mc * 4) sb[threadIdx.x] = __fmul_rn(boxes[(long)z * max_det * 4 + threadIdx.x], crop_scale);
+  __syncthreads();
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= npx) return;
+  f32x4 p[8];
+  const f32x4* src = reinterpret_cast<const f32x4*>(protos + ((long)z * npx + px) * 32);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) p[q] = src[q];
+  const int py = px / pw;
+  const float fx = (float)(px - py * pw), fy = (float)py;
+  for (int m = 0; m < mc; ++m) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 c = *reinterpret_cast<const f32x4*>(&sc[m * 32 + q * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(c[e], p[q][e], acc);
+    }
+    const bool inside = fx >= sb[m * 4] && fx < sb[m * 4 + 2] && fy >= sb[m * 4 + 1] && fy < sb[m * 4 + 3];
+    out[((long)z * mask_rows + m) * npx + px] = inside ? acc : 0.f;
+  }
+}
+
 // decode -> NMS -> mask logits of the kept detections
 void Detector::head_tail(int n, int* n_det, float* boxes, float* conf, int* cls, int* keep_idx, float* mask_logits, int mask_rows,
                          hipStream_t s) {
@@ -689,6 +725,12 @@ void Detector::head_tail(int n, int* n_det, float* boxes, float* conf, int* cls,
     // masks = coeffs @ protos^T per image, cropped to the box (process_mask / crop_mask)
     const View pr = view("protos");
     const int npx = pr.H * pr.W;
+    if (nm_ == 32 && mask_rows <= 16 && !count_flops_) {  // a handful of masks per frame: one pass over the prototypes
+      hipLaunchKernelGGL(mask_logits_kernel, dim3((unsigned)((npx + 255) / 256), (unsigned)n), dim3(256), 0, s, coef_, pr.p, n_det, boxes,
+                         mask_logits, npx, pr.W, mask_rows, cfg_.max_det, (float)pr.W / (float)S);
+      HIP_OK(hipGetLastError());
+      return;
+    }
     GemmArgs g = linear_args(coef_, nm_, pr.p, nullptr, mask_logits, npx, mask_rows, npx, nm_, ACT_NONE);
     g.batch = n;
     g.strideA = (long)cfg_.max_det * nm_;
