@@ -52,9 +52,13 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ r
     float v[16];
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      v[i] = row[s * 16 + i];
-      mx = fmaxf(mx, v[i]);
+    for (int q = 0; q < 4; ++q) {  // rows are RAW_CT = 100 floats: 16-byte loads (a lane's row shares no line with its neighbours')
+      const f32x4 t = *reinterpret_cast<const f32x4*>(row + s * 16 + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[q * 4 + e] = t[e];
+        mx = fmaxf(mx, t[e]);
+      }
     }
     float sum = 0.f;
 #pragma unroll
@@ -75,7 +79,15 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ r
   P[(long)2 * na] = (x2 - x1) * stride;
   P[(long)3 * na] = (y2 - y1) * stride;
   for (int c = 0; c < nc; ++c) P[(long)(4 + c) * na] = 1.0f / (1.0f + expf(-row[RAW_CLS + c]));
-  for (int c = 0; c < nm; ++c) P[(long)(4 + nc + c) * na] = row[RAW_COEF + c];
+  for (int c = 0; c < nm; c += 4) {
+    if (c + 4 <= nm) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(row + RAW_COEF + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) P[(long)(4 + nc + c + e) * na] = t[e];
+    } else {
+      for (int e = 0; c + e < nm; ++e) P[(long)(4 + nc + c + e) * na] = row[RAW_COEF + c + e];
+    }
+  }
 }
 
 // NHWC -> NCHW (raw protos for parity tests)
