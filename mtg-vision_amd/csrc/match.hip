@@ -61,6 +61,14 @@ Bank::Bank(int dim, int64_t capacity) : dim_(dim), cap_(capacity) {
   vecs_.alloc((size_t)capacity * dim);
   // the bank is the B operand of the match GEMM; rows of `dim` floats get per-row scaled split copies
   gemm_split_register(vecs_.p, (size_t)capacity * dim, dim % 8 == 0 ? dim : 0);
+  // workspace for the usual query batches up front (1024 queries, k <= 8, the candidate layout with the most groups:
+  // 64-column tiles), so that topk does not allocate on the hot path; larger requests still grow it once
+  const size_t groups = (size_t)ceil_div((int)capacity, 64);
+  if (groups * 8 * 1024 * sizeof(float) <= ((size_t)256 << 20)) {
+    qn_.ensure((size_t)1024 * dim);
+    cand_s_.ensure((size_t)1024 * groups * 8);
+    cand_i_.ensure((size_t)1024 * groups * 8);
+  }
 }
 
 Bank::~Bank() { gemm_split_unregister(vecs_.p); }
