@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: cards/sec end to end (detect + crop + embed + top-1 over a 100k x 768 bank).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]      (N > 1 from a plain shell: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -97,17 +97,47 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="one stream: detect(i) -> embed(i) strictly in sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-f32-roofline", action="store_true", help="skip the extra profiled passes in the f32 operand mode")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames in the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as a child `torch.distributed.run`, relay rank 0's
+    JSON line and return the child's exit code.  This parent never touches the GPU (no HIP call before or after)."""
+    import socket
+    import subprocess
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 or line is not None else 1
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run (see docstring)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the recognition path has no CPU fallback")
     # rehearsal on a one-GPU box: MTGV_SHARE_GPU=1 maps every rank to device 0 and MTGV_DIST_BACKEND=gloo
@@ -241,8 +271,25 @@ def main():
             "rest split when a fragment is read), 3 fp16 MFMAs per product, f32 accumulate (error vs fp64 at the f32 level, "
             "tests/test_gpu_precision.py)",
             "streams": "2 (detect of step i+1 beside embed+match of step i; MTGV_OVERLAP=on set by bench.py, the library default is 1)" if overlap else "1",
+            "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
+            "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
         },
     }
+    if overlap:
+        # the library default (one stream) on the same K steps, timed the same way: `value` is the faster configuration
+        # of the two, this is the other one
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            pipe.run(batches[i % NB])
+        barrier()
+        dt1 = time.perf_counter() - t0
+        if world > 1 or force_coll:
+            t = torch.tensor([dt1], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt1 = float(t.item())
+        res["config"]["one_stream_value"] = round(cards / dt1, 1)
+        res["config"]["one_stream_ms_per_step"] = round(dt1 / a.steps * 1e3, 3)
 
     # roofline leg.  Dominant kernel = gemm_f32_kernel (every conv / linear / bank GEMM of the path).  Every rank
     # runs two more passes of the same step, one stream, so that each launch is alone on the GPU and bracketed by HIP
@@ -251,9 +298,11 @@ def main():
 
     L = native.lib()
     prof = None
-    if not a.no_roofline:
-        native.check(L.mtgv_profile_gemm(1))
+    prof_f32 = None
+
+    def profile_pass(prec):
         nprof = 2
+        native.check(L.mtgv_profile_gemm(1))
         for i in range(nprof):
             pipe.run(batches[i % NB])
         torch.cuda.synchronize()
@@ -270,11 +319,23 @@ def main():
             native.check(L.mtgv_profile_gemm_dump(tmp_csv.encode()))
             recs = list(csv.DictReader(open(tmp_csv)))
             os.unlink(tmp_csv)
-            groups = group_launches(recs, nprof, precision)
+            groups = group_launches(recs, nprof, prec)
             fill_per_step = sum(float(r.get("fill", 0) or 0) for r in recs) / nprof
         native.check(L.mtgv_profile_gemm(0))
-        prof = (ms.value / nprof, fl.value / nprof, int(nl.value // nprof), by.value / nprof, groups, fill_per_step)
         barrier()
+        return (ms.value / nprof, fl.value / nprof, int(nl.value // nprof), by.value / nprof, groups, fill_per_step)
+
+    if not a.no_roofline:
+        prof = profile_pass(precision)
+        if precision == "f16x3" and not a.no_f32_roofline:
+            # the same step with exact f32-input MFMAs (the library's other operand mode): one warm pass, then the same
+            # two profiled passes; north_star's ">= 60 % of the MFMA roofline for the 1x1 / bank GEMMs" is stated against
+            # this mode's peak (157.3 TFLOP/s)
+            native.set_gemm_precision("f32")
+            pipe.run(batches[0])
+            torch.cuda.synchronize()
+            prof_f32 = profile_pass("f32")
+            native.set_gemm_precision("f16x3")
 
     if rank == 0:
         gflops_enc, dw_enc = encoder.flops_per_image()
@@ -331,6 +392,15 @@ def main():
                                   "ceiling_tbs": {"infinity_cache_resident": 8.6, "l2_resident": 17.8}, "unit": "TB/s"},
                 "measured": "HIP events around every launch on its stream, 2 single-stream passes after the timed region",
             }
+            if prof_f32 is not None:
+                ms32, fl32, n32, by32, groups32, _ = prof_f32
+                tf32 = fl32 / (ms32 * 1e-3) / 1e12 if ms32 > 0 else 0.0
+                res["roofline"]["f32_mode"] = {
+                    "what": "the same step after mtgv_set_gemm_precision(f32): every GEMM on v_mfma_f32_32x32x2_f32, same events",
+                    "bound": "mfma", "achieved": round(tf32, 2), "peak": PEAK_MFMA_TFLOPS["f32"], "unit": "TFLOP/s",
+                    "frac": round(tf32 / PEAK_MFMA_TFLOPS["f32"], 4), "gemm_ms_per_step": round(ms32, 3),
+                    "launches_per_step": n32, "groups": groups32,
+                }
         if world == 1 and not a.no_cpu_baseline:
             # bounded CPU sample of the same workload on the host cores: the oracle pipeline
             from oracle import pipeline_ref
@@ -373,7 +443,28 @@ def main():
             t0 = time.perf_counter()
             pipeline_ref.run(det_sd, det_cfg, enc_sd, enc_cfg, bank_cpu, fr, K)
             cdt = time.perf_counter() - t0
+            # per-stage detail on the same threads (batch 4 and 32; img/s, frames/s, queries/s), each a bounded sample
+            from oracle import detector_ref, encoder_ref, match_ref
+
+            stages = {}
+            g0 = np.random.default_rng(0)
+            h_, w_ = enc_cfg.image_hw
+            for nb_ in (4, 32):
+                xe = g0.random((nb_, 3, h_, w_), dtype=np.float32)
+                encoder_ref.encoder_forward(enc_sd, enc_cfg, xe[:1])
+                t0 = time.perf_counter()
+                encoder_ref.encoder_forward(enc_sd, enc_cfg, xe)
+                stages[f"encoder_img_per_s_batch{nb_}"] = round(nb_ / (time.perf_counter() - t0), 2)
+                fd = frames[:nb_].cpu().numpy()
+                t0 = time.perf_counter()
+                detector_ref.detect(det_sd, det_cfg, fd, True)
+                stages[f"detector_frames_per_s_batch{nb_}"] = round(len(fd) / (time.perf_counter() - t0), 2)
+                qd = g0.standard_normal((nb_, 768), dtype=np.float32)
+                t0 = time.perf_counter()
+                match_ref.cosine_topk(qd, bank_cpu, 1, dtype=np.float32)
+                stages[f"match_queries_per_s_batch{nb_}"] = round(nb_ / (time.perf_counter() - t0), 2)
             res["cpu_baseline"] = {
+                "stages": stages,
                 "value": round(cf * K / cdt, 2),
                 "unit": "cards/s",
                 "cores": nthreads,

@@ -45,9 +45,10 @@ MTGV_API int mtgv_device_count(void);
  *   MTGV_PREC_F16X3 (1)  each f32 operand represented as fp16 hi + lo; three fp16 matrix instructions per
  *                        product, f32 accumulate.  Error vs fp64 at the f32 level, ~2x the GEMM rate.  Weights carry
  *                        a power-of-two scale per output row (undone in the accumulator), so their magnitude does
- *                        not matter; activations inside the handles are O(1) by construction; the single-op entry
- *                        points (mtgv_op_*) rescale inputs beyond 2^14 by a power of two.  Values that still leave
- *                        the fp16 range turn into inf - visible, never silently wrong.
+ *                        not matter; activations inside the handles are O(1) by construction; mtgv_op_linear, which
+ *                        takes arbitrary f32 data, rescales inputs beyond 2^14 by a power of two (the other mtgv_op_*
+ *                        entry points expect activations within the fp16 range, as the handles produce them).
+ *                        Values that leave the fp16 range turn into inf - visible, never silently wrong.
  * The initial value comes from the environment (MTGV_GEMM_PREC=f32|f16x3, default f16x3).  Both
  * meet the path's 1e-4 contract against the reference (tests/test_gpu_precision.py).  Not thread-safe: set it
  * before the worker threads start.
@@ -55,11 +56,19 @@ MTGV_API int mtgv_device_count(void);
  * arithmetic (v_pk_mul_f32, v_pk_fma_f32) and run on ANOTHER STREAM of the same GPU while F16X3 launches are in
  * flight can get wrong lanes.  This library is built without those instructions and by itself keeps every launch
  * on the caller's stream (mtgv.Pipeline overlaps two streams only with MTGV_OVERLAP=on, and then runs nothing but
- * library kernels on them).  A caller that runs foreign kernels (PyTorch elementwise ops included) concurrently on
+ * library kernels on them: its output tensors are uninitialised allocations filled by the kernels, the glue between
+ * the stages is mtgv_select_cards).  A caller that runs foreign kernels (PyTorch elementwise ops included) concurrently on
  * a second stream must either serialise them against the library's stream or select MTGV_PREC_F32. */
 #define MTGV_PREC_F32 0
 #define MTGV_PREC_F16X3 1
 MTGV_API int mtgv_set_gemm_precision(int32_t prec);
+/* The one kernel of the library that exists in a packed-FP32 build as well (depthwise 7x7 + LayerNorm, VALU-bound on its
+ * stencil: v_pk_fma_f32 halves the instruction count, results bit-identical) is subject to the same contract from the
+ * other side: it is launched only while the process states that the library's launches are not concurrent with F16X3
+ * launches of another stream or process on the same GPU.  Initial value: MTGV_PACKED_FP32=0|1 if set, else 1 unless
+ * MTGV_OVERLAP=on.  Not thread-safe: set it while no library call is in flight. */
+MTGV_API int mtgv_set_packed_fp32(int32_t allow);
+MTGV_API int mtgv_get_packed_fp32(void);
 MTGV_API int mtgv_get_gemm_precision(int32_t* prec);
 
 /* Measurement aid: when enabled, every launch of the GEMM kernel is bracketed by HIP
@@ -142,12 +151,14 @@ MTGV_API int mtgv_bank_clear(mtgv_bank* h);
 /* copy stored (normalised) rows [row, row+n) to out_host */
 MTGV_API int mtgv_bank_get_rows(const mtgv_bank* h, int64_t row, int64_t n, float* out_host);
 /* q_dev: (b, dim) raw query vectors.  Writes ids (b,k) int64 (row index + id_base, -1 = none)
- * and scores (b,k) float32, sorted by score desc then id asc. */
-MTGV_API int mtgv_bank_topk(mtgv_bank* h, const float* q_dev, int32_t b, int32_t k, int64_t id_base, int64_t* ids_dev,
-                            float* scores_dev, void* stream);
-/* merge ncand (score,id) candidates per query into the top k (multi-GPU shard merge) */
+ * and scores (b,k) float32, sorted by score desc then id asc.  score_threshold is query_nearby's
+ * (mtgvision/qdrant.py:83,93): hits scoring below it are dropped on the device (id -1 / score -inf, like a bank with
+ * fewer than k rows); -INFINITY keeps everything, NaN is rejected. */
+MTGV_API int mtgv_bank_topk(mtgv_bank* h, const float* q_dev, int32_t b, int32_t k, int64_t id_base, float score_threshold,
+                            int64_t* ids_dev, float* scores_dev, void* stream);
+/* merge ncand (score,id) candidates per query into the top k (multi-GPU shard merge); same threshold rule */
 MTGV_API int mtgv_topk_merge(float* cand_scores_dev, const int64_t* cand_ids_dev, int32_t b, int32_t ncand, int32_t k,
-                             int64_t* ids_dev, float* scores_dev, void* stream);
+                             float score_threshold, int64_t* ids_dev, float* scores_dev, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Detector: YOLOv8n-seg forward + decode + NMS + mask logits.                */
@@ -207,7 +218,13 @@ MTGV_API size_t mtgv_nms_workspace_bytes(int32_t n, int32_t na);
 /* masks_dev (n, h, w) uint8, non-zero = foreground (mtgv_mask_binarize output); boxes_dev (n, 4) xyxy float32 or NULL:
  * the quad reported for an empty mask.  quads_dev (n, 4, 2) float32 corners (x, y) in pixels of the mask grid, ordered
  * top-left, top-right, bottom-right, bottom-left of the card; ok_dev (n) int32: 1 = from the mask, 0 = empty mask.
- * The quad is the minimum-area rectangle of the mask's convex hull; "up" is mask centroid minus hull centroid. */
+ * The quad is the general quadrilateral cv2.approxPolyN(hull, 4) fits (od_export.py:72-74): the convex hull of the mask's
+ * row extents, greedily contracted edge by edge (the edge whose removal adds the least area is replaced by the
+ * intersection of its neighbours, first minimum wins) until four vertices remain - vertices may therefore lie outside
+ * the mask, or outside the image; coordinates are truncated toward zero as the reference's astype(int) does.  "Up" is
+ * mask centroid minus hull centroid: the ray from the quad's centre along it picks the card's top edge.  Fallbacks: a
+ * hull of fewer than four vertices (point, line, triangle) reports the mask's bounding box; an empty mask reports
+ * boxes_dev[n] (or zeros) with ok = 0. */
 MTGV_API int mtgv_mask_quads(const uint8_t* masks_dev, int32_t n, int32_t h, int32_t w, const float* boxes_dev, float* quads_dev,
                              int32_t* ok_dev, void* stream);
 /* the same from the cropped mask logits (n, mh, mw) of the detector: a pixel of the (mh*scale, mw*scale) mask is foreground
@@ -215,6 +232,15 @@ MTGV_API int mtgv_mask_quads(const uint8_t* masks_dev, int32_t n, int32_t h, int
  * never materialised.  Identical quads to mtgv_mask_binarize + mtgv_mask_quads. */
 MTGV_API int mtgv_mask_quads_logits(const float* logits_dev, int32_t n, int32_t mh, int32_t mw, int32_t scale,
                                     const float* boxes_dev, float* quads_dev, int32_t* ok_dev, void* stream);
+
+/* The K cards of every frame that go on to the crop stage: the K highest-confidence detections of the padded
+ * mtgv_detector_forward outputs (n_det (frames), boxes (frames, max_det, 4), score-descending) or, where a frame has
+ * fewer, pad_boxes_dev[k] (k, 4).  Writes sel_boxes_dev (frames*k, 4) xyxy, frame_idx_dev (frames*k) and, unless null,
+ * quads_dev (frames*k, 4, 2): the boxes' corners in the order mtgv_warp_quads expects.  The glue between
+ * `results.boxes` and `extract_dewarped` (mtgvision/od_export.py:152-160, server.py:139-183), batched. */
+MTGV_API int mtgv_select_cards(const int32_t* n_det_dev, const float* boxes_dev, const float* pad_boxes_dev, int32_t frames,
+                               int32_t max_det, int32_t k, float* sel_boxes_dev, float* quads_dev, int32_t* frame_idx_dev,
+                               void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Crop: perspective de-warp of card quads.                                   */

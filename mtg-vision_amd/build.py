@@ -33,6 +33,7 @@ FLAGS = [
     "-I",
     CSRC,
     "-Wno-unused-result",
+    "-Wno-inline-asm",  # sp_dma16_saddr (sp8.h) names M0 as clobbered on purpose
     # No packed-FP32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 ...) in device code.  Measured on MI355X: a wave
     # executing them beside the split-precision GEMM of another stream (v_cvt_pk_f16_f32 + f16 MFMA on the same SIMD)
     # sporadically lost the low half of a packed result in one 16-lane group (tests/test_gpu_overlap.py:
@@ -68,7 +69,11 @@ def build(force: bool = False, jobs: int = 6, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+        flags = list(FLAGS)
+        if src.endswith("_pk.hip"):  # the one translation unit built WITH packed-FP32 instructions (rowops_pk.hip)
+            i = flags.index("-packed-fp32-ops")
+            del flags[i - 3 : i + 1]
+        cmd = [HIPCC, *flags, "-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 
 #include "encoder.h"
 #include "match.h"
@@ -20,10 +21,15 @@ using namespace mtgv;
 namespace {
 // The single-op entry points take raw weight pointers.  To run them on the same kernels the handles use, a constant
 // operand is registered (SP8 copy + row scales) for the duration of the call; the call then synchronises the stream.
+// Temporary registrations are visible to every thread through the registry: the single-op entry points therefore run
+// one at a time (a process-wide lock held from before the lookup until the temporary copy has been released), so no
+// other call can pick up a copy that is about to be freed.
+std::recursive_mutex g_op_mu;
 struct ScopedWeights {
   const float* w = nullptr;
   hipStream_t s;
-  ScopedWeights(const float* W, int n, int k, hipStream_t stream) : s(stream) {
+  std::unique_lock<std::recursive_mutex> lk;
+  ScopedWeights(const float* W, int n, int k, hipStream_t stream) : s(stream), lk(g_op_mu) {
     if (W == nullptr || k % 8 != 0 || gemm_precision() != GEMM_PREC_F16X3 || ((uintptr_t)W % 16) != 0) return;
     if (sp8_lookup(W, k, nullptr, nullptr)) return;  // the caller already owns a registration
     sp8_register(W, (size_t)n * k, k);
@@ -51,7 +57,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 // the single-op entry points take arbitrary f32 data, the handles know their activations are LayerNorm outputs etc.
 void range_guard(GemmArgs& g, const float* a_dev, long n, hipStream_t s) {
   if (gemm_precision() != GEMM_PREC_F16X3 || n <= 0) return;
-  static unsigned* d_max = nullptr;
+  static unsigned* d_max_dev[MTGV_MAX_DEVICES] = {};  // one scratch word per device
+  unsigned*& d_max = d_max_dev[current_device()];
   if (d_max == nullptr) HIP_OK(hipMalloc((void**)&d_max, sizeof(unsigned)));
   HIP_OK(hipMemsetAsync(d_max, 0, sizeof(unsigned), s));
   const unsigned grid = (unsigned)std::min<long>((n + 255) / 256, 1024);
@@ -98,6 +105,11 @@ MTGV_API int mtgv_get_gemm_precision(int32_t* prec) {
     *prec = gemm_precision();
   });
 }
+
+MTGV_API int mtgv_set_packed_fp32(int32_t allow) {
+  return guarded([&] { set_packed_fp32(allow); });
+}
+MTGV_API int mtgv_get_packed_fp32(void) { return packed_fp32_allowed() ? 1 : 0; }
 
 // ---- GEMM launch profiler ----
 MTGV_API int mtgv_profile_gemm(int32_t enable) {
@@ -204,18 +216,20 @@ MTGV_API int mtgv_bank_get_rows(const mtgv_bank* h, int64_t row, int64_t n, floa
     h->impl.get_rows(row, n, out_host);
   });
 }
-MTGV_API int mtgv_bank_topk(mtgv_bank* h, const float* q_dev, int32_t b, int32_t k, int64_t id_base, int64_t* ids_dev,
-                            float* scores_dev, void* stream) {
+MTGV_API int mtgv_bank_topk(mtgv_bank* h, const float* q_dev, int32_t b, int32_t k, int64_t id_base, float score_threshold,
+                            int64_t* ids_dev, float* scores_dev, void* stream) {
   return guarded([&] {
     MTGV_CHECK(h != nullptr, ERR_INVALID, "null handle");
-    h->impl.topk(q_dev, b, k, id_base, ids_dev, scores_dev, (hipStream_t)stream);
+    MTGV_CHECK(!(score_threshold != score_threshold), ERR_INVALID, "bank: score_threshold is NaN");
+    h->impl.topk(q_dev, b, k, id_base, score_threshold, ids_dev, scores_dev, (hipStream_t)stream);
   });
 }
 MTGV_API int mtgv_topk_merge(float* cand_scores_dev, const int64_t* cand_ids_dev, int32_t b, int32_t ncand, int32_t k,
-                             int64_t* ids_dev, float* scores_dev, void* stream) {
+                             float score_threshold, int64_t* ids_dev, float* scores_dev, void* stream) {
   return guarded([&] {
     MTGV_CHECK(cand_scores_dev && cand_ids_dev && ids_dev && scores_dev, ERR_INVALID, "null argument");
-    topk_merge_launch_i64(cand_scores_dev, cand_ids_dev, b, ncand, k, ids_dev, scores_dev, (hipStream_t)stream);
+    MTGV_CHECK(!(score_threshold != score_threshold), ERR_INVALID, "topk_merge: score_threshold is NaN");
+    topk_merge_launch_i64(cand_scores_dev, cand_ids_dev, b, ncand, k, score_threshold, ids_dev, scores_dev, (hipStream_t)stream);
   });
 }
 
@@ -263,9 +277,10 @@ MTGV_API int mtgv_op_linear_ex(const float* a_dev, const float* w_dev, const flo
     }
     const GemmPlan pl = gemm_plan(m, n, k, act != 0, a_scale_dev != nullptr);
     if (grn_part_dev) {
+      g.grn_part = grn_part_dev;  // before the layout: the kernel choice depends on it
       t_last_grn = gemm_grn_layout(g, pl);
-      g.grn_part = grn_part_dev;
       g.segmax = t_last_grn.segmax;
+      g.grn_unit_rows = t_last_grn.unit_rows;
     }
     gemm_launch(g, pl, (hipStream_t)stream);
   });

@@ -68,6 +68,16 @@ __host__ __device__ static inline uint32_t fdiv(uint32_t n, const FastDiv& f) {
   return (uint32_t)(((uint64_t)n * f.mul) >> 40);
 }
 
+// Per-device lazily created state (zero pages, function attributes, scratch words) is kept in small tables indexed by
+// the HIP device ordinal: a handle is bound to the device current at its creation and several may coexist in a process.
+constexpr int MTGV_MAX_DEVICES = 64;
+static inline int current_device() {
+  int d = 0;
+  HIP_OK(hipGetDevice(&d));
+  MTGV_CHECK(d >= 0 && d < MTGV_MAX_DEVICES, ERR_RUNTIME, "device ordinal %d outside [0, %d)", d, MTGV_MAX_DEVICES);
+  return d;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -690,7 +690,7 @@ void Detector::proto(const std::string& H, const View& p3, int n, hipStream_t s)
 // Mask logits of a few detections per frame (process_mask + crop_mask behind od_export.py:152): out[z][m][px] =
 // <coef[z][m], protos[z][px]> inside box m, 0 outside - f32 FMA chain in k order.  One thread per prototype pixel reads
 // its 32 channels once (128 contiguous bytes) and serves all the frame's kept rows; coefficients and scaled boxes sit in
-// LDS.  Rows beyond n_det[z] are left untouched, as the batched GEMM it replaces for small row counts did.
+// LDS.  Rows beyond n_det[z] are written as zeros (empty masks).
 __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restrict__ coef, const float* __restrict__ protos,
                                                          const int* __restrict__ n_det, const float* __restrict__ boxes,
                                                          float* __restrict__ out, int npx, int pw, int mask_rows, int max_det,
@@ -721,6 +721,7 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
     const bool inside = fx >= sb[m * 4] && fx < sb[m * 4 + 2] && fy >= sb[m * 4 + 1] && fy < sb[m * 4 + 3];
     out[((long)z * mask_rows + m) * npx + px] = inside ? acc : 0.f;
   }
+  for (int m = mc; m < mask_rows; ++m) out[((long)z * mask_rows + m) * npx + px] = 0.f;
 }
 
 // decode -> NMS -> mask logits of the kept detections
@@ -743,6 +744,8 @@ void Detector::head_tail(int n, int* n_det, float* boxes, float* conf, int* cls,
       HIP_OK(hipGetLastError());
       return;
     }
+    // the batched GEMM writes only the rows of kept detections: the rest is cleared first
+    HIP_OK(hipMemsetAsync(mask_logits, 0, (size_t)n * mask_rows * npx * sizeof(float), s));
     GemmArgs g = linear_args(coef_, nm_, pr.p, nullptr, mask_logits, npx, mask_rows, npx, nm_, ACT_NONE);
     g.batch = n;
     g.strideA = (long)cfg_.max_det * nm_;

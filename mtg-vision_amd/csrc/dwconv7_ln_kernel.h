@@ -1,0 +1,142 @@
+// Depthwise 7x7 + LayerNorm kernel body, shared by two translation units: rowops.hip (built like the rest of the library,
+// without packed-FP32 VALU instructions) and rowops_pk.hip (packed FP32 allowed: v_pk_fma_f32 does two of the stencil's
+// FMAs per instruction).  PK only keeps the two instantiations apart at link time.
+#pragma once
+#include "common.h"
+#include "sp8.h"
+
+namespace mtgv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// Depthwise 7x7 + LayerNorm over C in one pass (Block.dwconv + Block.norm, convnextv2.py:214-216): the conv
+// result never goes to HBM un-normalised.  A block owns S whole strips (all C channels of TW pixels), so the
+// per-pixel mean / variance over channels are block-local: partial sums go through LDS in a fixed order
+// (two-pass variance like ln_rows_kernel, deterministic).
+// ---------------------------------------------------------------------------
+template <int TW, bool SP8, int PK>
+__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ in, const float* __restrict__ w49,
+                                                        const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                        const float* __restrict__ ln_b, float* __restrict__ out, int H, int W,
+                                                        int C, int nstrips, long total_strips, int S, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int c4n = C >> 2;
+  float* part = sm;                      // [S][TW][c4n]
+  float* stat = sm + S * TW * c4n;       // [S][TW][2] mean, rstd
+  long blk;
+  {
+    const long nwg = gridDim.x, b = blockIdx.x;
+    const long q = nwg >> 3, r = nwg & 7, x = b & 7;
+    blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  const int tid = threadIdx.x;
+  const int sl = tid / c4n, c4 = tid % c4n;  // strip slot in block, channel quad
+  const long strip = blk * S + sl;
+  const bool live = sl < S && strip < total_strips;
+  const int c = c4 * 4;
+  int ws = 0, h = 0;
+  long n = 0;
+  if (live) {
+    ws = (int)(strip % nstrips);
+    const long t = strip / nstrips;
+    h = (int)(t % H);
+    n = t / H;
+  }
+  const int w0 = ws * TW;
+  f32x4 acc[TW];
+  if (live) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+    for (int j = 0; j < TW; ++j) acc[j] = bv;
+#pragma unroll 1
+    for (int kh = 0; kh < 7; ++kh) {
+      const int ih = h + kh - 3;
+      if (ih < 0 || ih >= H) continue;
+      const float* rowp = in + ((n * H + ih) * W) * C + c;
+      f32x4 r[TW + 6];
+#pragma unroll
+      for (int j = 0; j < TW + 6; ++j) {
+        const int iw = w0 + j - 3;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iw >= 0 && iw < W) v = *reinterpret_cast<const f32x4*>(rowp + (long)iw * C);
+        r[j] = v;
+      }
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w49 + (kh * 7 + kw) * C + c);
+#pragma unroll
+        for (int j = 0; j < TW; ++j) acc[j] += r[j + kw] * wv;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TW; ++j) part[(sl * TW + j) * c4n + c4] = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+  }
+  __syncthreads();
+  if (live && c4 < TW) {  // thread c4 of a strip reduces pixel j = c4
+    const float* pp = part + (sl * TW + c4) * c4n;
+    float sum = 0.f;
+    for (int i = 0; i < c4n; ++i) sum += pp[i];
+    stat[(sl * TW + c4) * 2] = sum / (float)C;
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+      const f32x4 d = acc[j] - stat[(sl * TW + j) * 2];
+      part[(sl * TW + j) * c4n + c4] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  __syncthreads();
+  if (live && c4 < TW) {
+    const float* pp = part + (sl * TW + c4) * c4n;
+    float sq = 0.f;
+    for (int i = 0; i < c4n; ++i) sq += pp[i];
+    stat[(sl * TW + c4) * 2 + 1] = 1.0f / sqrtf(sq / (float)C + eps);
+  }
+  __syncthreads();
+  if (live) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(ln_w + c);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(ln_b + c);
+    float* op = out + ((n * H + h) * W + w0) * C + c;
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+      if (w0 + j < W) {
+        const float mean = stat[(sl * TW + j) * 2], rstd = stat[(sl * TW + j) * 2 + 1];
+        const f32x4 o = (acc[j] - mean) * rstd * wv + bv;
+        if (SP8)  // quads c4, c4^1 of a strip are adjacent lanes with the same predicates (C % 8 == 0)
+          *reinterpret_cast<sp_h8*>(reinterpret_cast<char*>(op + (long)j * C - c) + (c4 >> 1) * 32 + (c4 & 1) * 16) =
+              sp8_piece_from_quad(o, c4);
+        else
+          *reinterpret_cast<f32x4*>(op + (long)j * C) = o;
+      }
+  }
+}
+
+
+template <int PK>
+static void dwconv7_ln_launch_t(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b,
+                                float* out, int N, int H, int W, int C, float eps, hipStream_t s, int out_fmt) {
+  const int tw = W >= 8 ? 8 : (W >= 4 ? 4 : 2);
+  const int nstrips = ceil_div(W, tw);
+  const int c4n = C / 4;
+  const int S = 256 / c4n;
+  const long total_strips = (long)N * H * nstrips;
+  const unsigned grid = (unsigned)((total_strips + S - 1) / S);
+  const size_t lds = (size_t)(S * tw * c4n + S * tw * 2) * sizeof(float);
+#define DWLN_GO(TW_, SP_) \
+  hipLaunchKernelGGL((dwconv7_ln_kernel<TW_, SP_, PK>), dim3(grid), dim3(256), lds, s, in, w49, bias, ln_w, ln_b, out, H, W, C, nstrips, total_strips, S, eps)
+  if (out_fmt == 1) {
+    if (tw == 8) DWLN_GO(8, true);
+    else if (tw == 4) DWLN_GO(4, true);
+    else DWLN_GO(2, true);
+  } else {
+    if (tw == 8) DWLN_GO(8, false);
+    else if (tw == 4) DWLN_GO(4, false);
+    else DWLN_GO(2, false);
+  }
+#undef DWLN_GO
+  HIP_OK(hipGetLastError());
+}
+
+}  // namespace mtgv

@@ -31,6 +31,9 @@ struct BlockW {
   float *w1 = nullptr, *b1 = nullptr, *gamma = nullptr, *beta = nullptr, *w2 = nullptr, *b2 = nullptr;
   // b2 + W2 . beta: the GRN shift folded into the pwconv2 bias at load time (null -> shift applied in the A prologue)
   float* b2_folded = nullptr;
+  // fused MLP path (mlp_fused.h): W2 in the k order of the fused kernel's operand + its row scales; null -> packed per call
+  const void* w2p = nullptr;
+  const float* w2p_scale = nullptr;
 };
 struct BlockWs {
   float *t1 = nullptr, *t2 = nullptr, *hid = nullptr, *part = nullptr, *scale = nullptr, *bfold = nullptr;
@@ -109,7 +112,7 @@ class Encoder {
   int last_n_ = 0;
   bool prepared_ = false;
   std::vector<std::string> blk_prefix_[4];
-  DevBuf folded_bias_;
+  DevBuf folded_bias_, w2p_;
   void prepare();
   void body(int n, float* z_out, hipStream_t s);
   int graph_mode_ = 0, graph_max_n_ = 16;

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include "rowops.h"
 #include "gemm_sp.h"
+#include "mlp_fused.h"
 
 #include <string.h>
 
@@ -146,13 +147,35 @@ void run_block(const float* x, float* out, int n, int h, int w, int c, int act, 
     ln_rows_launch(ws.t1, c, 0, ws.t2, c, 0, bw.ln_w, bw.ln_b, M, c, 1e-6f, s, fmt);
   }
 
+  if (fmt == 1 && mlp_fused_supported(c, hw, act)) {
+    // narrow stage: pwconv1 + GRN + pwconv2 without the 4C hidden tensor in HBM (mlp_fused_kernel.h)
+    MlpArgs m;
+    m.x_sp8 = ws.t2, m.w1 = bw.w1, m.b1 = bw.b1, m.gamma = bw.gamma, m.res = x, m.out = out;
+    m.part = ws.part, m.scale = ws.scale, m.n_img = n, m.hw = hw, m.C = c, m.act = act;
+    if (bw.w2p != nullptr) {
+      m.w2p = bw.w2p, m.ws2 = bw.w2p_scale;
+    } else {  // single-op surface: the permuted copy of W2 is made per call, in the (unused) hidden-tensor workspace
+      mlp_pack_w2p_launch(bw.w2, ws.hid, ws.hid + (size_t)c * 4 * c, c, s);
+      m.w2p = ws.hid, m.ws2 = ws.hid + (size_t)c * 4 * c;
+    }
+    if (bw.b2_folded != nullptr) {
+      m.b2 = bw.b2_folded;
+    } else {
+      fold_shift_into_bias_launch(bw.w2, bw.beta, bw.b2, ws.bfold, c, 4 * c, s);
+      m.b2 = ws.bfold;
+    }
+    mlp_fused_launch(m, s);
+    return;
+  }
+
   GemmArgs g1 = linear_args(ws.t2, c, bw.w1, bw.b1, ws.hid, 4 * c, M, 4 * c, c, act);
   g1.a_fmt = fmt;
   const GemmPlan p1 = gemm_plan(M, 4 * c, c, true);
   g1.hw = hw;
+  g1.grn_part = ws.part;  // set before the layout is computed: which kernel takes the launch depends on it
   const GrnLayout gl = gemm_grn_layout(g1, p1);
-  g1.grn_part = ws.part;
   g1.segmax = gl.segmax;
+  g1.grn_unit_rows = gl.unit_rows;
   gemm_launch(g1, p1, s);
 
   grn_finalize_launch(ws.part, gl, n, hw, 4 * c, bw.gamma, ws.scale, s);
@@ -335,6 +358,25 @@ void Encoder::prepare() {
     }
   }
   HIP_OK(hipMemcpy(folded_bias_.p, all.data(), total * sizeof(float), hipMemcpyHostToDevice));
+  // permuted SP8 copies of pwconv2.weight for the stages the fused MLP kernel can take (any operand mode: the mode can
+  // be switched after the weights are loaded)
+  size_t w2p_floats = 0;
+  for (int s = 0; s < 4; ++s)
+    if (cfg_.dims[s] == 96 || cfg_.dims[s] == 80) w2p_floats += blocks_[s].size() * ((size_t)cfg_.dims[s] * 4 * cfg_.dims[s] + cfg_.dims[s]);
+  if (w2p_floats > 0) {
+    w2p_.ensure(w2p_floats);
+    float* p = w2p_.p;
+    for (int s = 0; s < 4; ++s) {
+      const int c = cfg_.dims[s];
+      if (!(c == 96 || c == 80)) continue;
+      for (auto& b : blocks_[s]) {
+        mlp_pack_w2p_launch(b.w2, p, p + (size_t)c * 4 * c, c, nullptr);
+        b.w2p = p, b.w2p_scale = p + (size_t)c * 4 * c;
+        p += (size_t)c * 4 * c + c;
+      }
+    }
+    HIP_OK(hipStreamSynchronize(nullptr));
+  }
   prepared_ = true;
 }
 

@@ -50,6 +50,7 @@ struct GemmArgs {
   float* grn_part = nullptr;    // [tiles_m][segmax][N]
   int hw = 0;                   // rows per image for GRN / prologue segmentation
   int segmax = 0;
+  int grn_unit_rows = 0;        // rows per partial unit the caller planned for (GrnLayout::unit_rows); 0: not checked
   // GRN apply fused into the A load of pwconv2: a' = a * a_scale[img][k] + a_shift[k]
   const float* a_scale = nullptr;
   const float* a_shift = nullptr;
@@ -111,6 +112,10 @@ bool gemm_profile_enabled();
 void gemm_profile_read(double* ms, double* flops, long* launches);
 void gemm_profile_dump(const char* path);
 double gemm_profile_bytes();  // compulsory operand + result bytes of the launches recorded since enable
+// For launches that do the work of a GEMM layer outside gemm_launch (mlp_fused.hip): record `a`'s shape (M, N, K, act,
+// a_scale / grn_part / res as flags) with the given LDS fill and compulsory bytes, bracketed by events on s.
+void gemm_profile_begin(const GemmArgs& a, hipStream_t s, int sp, double fill, double bytes);
+void gemm_profile_end(hipStream_t s);
 
 // Layout of the GRN partial sums a launch with these arguments writes (grn_part itself need not be set yet):
 // [ceil(M / unit_rows)][segmax][N] floats.  Depends on which kernel gemm_launch will pick for the arguments.

@@ -88,7 +88,7 @@ void gemm_profile_read(double* ms, double* flops, long* launches) {
 }
 
 // fill: bytes the launch's tiles pull into LDS (every tile its A and B panels; 4 bytes per element in either format)
-static void prof_begin(const GemmArgs& a, hipStream_t s, int sp, double fill) {
+static void prof_begin(const GemmArgs& a, hipStream_t s, int sp, double fill, double bytes_override = -1.0) {
   if (!g_prof.on) return;
   while (g_prof.ev.size() < g_prof.used + 2) {
     hipEvent_t e;
@@ -103,8 +103,9 @@ static void prof_begin(const GemmArgs& a, hipStream_t s, int sp, double fill) {
     const double w_el = (double)a.N * a.K;
     const double o_el = a.topk > 0 ? (double)a.M * ceil_div(a.N, 64) * a.topk * 2 : (double)a.M * a.N;
     const double r_el = a.res != nullptr ? (double)a.M * a.N : 0.0;
-    const double by = 4.0 * ((a.strideA != 0 || a.batch == 1 ? a.batch : 1) * a_el + (a.strideW != 0 || a.batch == 1 ? a.batch : 1) * w_el +
-                             a.batch * (o_el + r_el));
+    double by = 4.0 * ((a.strideA != 0 || a.batch == 1 ? a.batch : 1) * a_el + (a.strideW != 0 || a.batch == 1 ? a.batch : 1) * w_el +
+                       a.batch * (o_el + r_el));
+    if (bytes_override >= 0.0) by = bytes_override;
     g_prof.bytes += by;
     g_prof.recs.push_back({a.M, a.N, a.K, a.KH, a.stride, a.batch, a.act, a.a_scale != nullptr, a.grn_part != nullptr, a.topk, sp, by, fill});
   }
@@ -115,6 +116,8 @@ static void prof_end(hipStream_t s) {
   HIP_OK(hipEventRecord(g_prof.ev[g_prof.used + 1], s));
   g_prof.used += 2;
 }
+void gemm_profile_begin(const GemmArgs& a, hipStream_t s, int sp, double fill, double bytes) { prof_begin(a, s, sp, fill, bytes); }
+void gemm_profile_end(hipStream_t s) { prof_end(s); }
 
 // ---------------------------------------------------------------------------
 // pre-split weight registry (f16x3)
@@ -340,7 +343,11 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
       return;
     }
   }
-  if (a.grn_part) MTGV_CHECK(a.segmax >= gemm_grn_segmax(pl, a.hw), ERR_INVALID, "gemm: segmax too small");
+  if (a.grn_part) {
+    MTGV_CHECK(a.segmax >= gemm_grn_segmax(pl, a.hw), ERR_INVALID, "gemm: segmax too small");
+    MTGV_CHECK(a.grn_unit_rows == 0 || a.grn_unit_rows == pl.bm(), ERR_RUNTIME,
+               "gemm: GRN partials planned for %d-row units, this launch writes %d-row units", a.grn_unit_rows, pl.bm());
+  }
 
   GemmDev g;
   g.a = a;

@@ -576,7 +576,8 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
 template <int TM, int TN, int BK, bool CONV, bool APRO, int EPI, int ACT, int PREC>
 static void launch_one(const GemmDev& g, int grid, hipStream_t s) {
   const size_t lds = gemm_lds_bytes<TM, TN, BK, APRO, PREC>(g.nseg_max);
-  static bool attr_done = false;  // only a launch that needs more than 64 KiB of dynamic LDS has to opt in
+  static bool attr_done_dev[MTGV_MAX_DEVICES] = {};  // hipFuncSetAttribute is per device
+  bool& attr_done = attr_done_dev[current_device()];  // only a launch that needs more than 64 KiB of dynamic LDS has to opt in
   if (lds > 64 * 1024 && !attr_done) {
     HIP_OK(hipFuncSetAttribute((const void*)gemm_f32_kernel<TM, TN, BK, CONV, APRO, EPI, ACT, PREC>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

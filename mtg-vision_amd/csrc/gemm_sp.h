@@ -33,6 +33,9 @@ bool gemm_sp_topk_layout(const GemmArgs& a, int* slots, int* cols);  // candidat
 double gemm_sp_fill_bytes(const GemmArgs& a, const SpPlan& pl);  // LDS fill bytes of the launch (profiling aid)
 void gemm_sp_stamps_dump(const char* path);  // tuning aid, see gemm_sp.hip
 
+// >= 256 zero bytes on the current device (K tails and padding taps of the DMA paths read them)
+const char* sp_zero_page();
+
 // f32 [rows][K] -> SP8 rows, unscaled (activations; test surface)
 void sp8_pack_plain_launch(const float* in, void* out, long rows, int K, hipStream_t s);
 

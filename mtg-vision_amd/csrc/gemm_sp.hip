@@ -73,17 +73,18 @@ struct Sp8Entry {
 };
 std::map<const float*, Sp8Entry> g_sp8;
 std::mutex g_sp8_mu;
-char* g_zero = nullptr;
-
-const char* zero_page() {
-  std::lock_guard<std::mutex> lk(g_sp8_mu);
-  if (g_zero == nullptr) {
-    HIP_OK(hipMalloc((void**)&g_zero, 256));
-    HIP_OK(hipMemset(g_zero, 0, 256));
-  }
-  return g_zero;
-}
+char* g_zero[MTGV_MAX_DEVICES] = {};  // one zero page per device: a handle may live on any GPU of the process (mtgv.h)
 }  // namespace
+
+const char* sp_zero_page() {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(g_sp8_mu);
+  if (g_zero[dev] == nullptr) {
+    HIP_OK(hipMalloc((void**)&g_zero[dev], 256));
+    HIP_OK(hipMemset(g_zero[dev], 0, 256));
+  }
+  return g_zero[dev];
+}
 
 void sp8_register(const float* W, size_t n_floats, int row_k) {
   if (W == nullptr || row_k <= 0 || row_k % 8 != 0 || n_floats == 0 || n_floats % (size_t)row_k != 0 || ((uintptr_t)W % 16) != 0) return;
@@ -92,10 +93,16 @@ void sp8_register(const float* W, size_t n_floats, int row_k) {
   if (e.buf != nullptr && e.n == n_floats && e.row_k == row_k) return;
   if (e.buf != nullptr) (void)hipFree(e.buf);
   if (e.wscale != nullptr) (void)hipFree(e.wscale);
+  e.buf = nullptr, e.wscale = nullptr;
   e.n = n_floats;
   e.row_k = row_k;
-  HIP_OK(hipMalloc((void**)&e.buf, n_floats * sizeof(float)));
-  HIP_OK(hipMalloc((void**)&e.wscale, (n_floats / row_k) * sizeof(float)));
+  // a failed allocation must not leave an entry that lookups would report as a valid copy
+  if (hipMalloc((void**)&e.buf, n_floats * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&e.wscale, (n_floats / row_k) * sizeof(float)) != hipSuccess) {
+    if (e.buf != nullptr) (void)hipFree(e.buf);
+    g_sp8.erase(W);
+    MTGV_CHECK(false, ERR_RUNTIME, "sp8_register: out of device memory for %zu floats", n_floats);
+  }
 }
 
 void sp8_refresh(const float* W, size_t offset_floats, size_t n_floats, hipStream_t s) {
@@ -132,7 +139,7 @@ bool sp8_lookup(const float* W, int K, const char** sp8, const float** wscale) {
   --it;
   const Sp8Entry& e = it->second;
   const size_t off = (size_t)(W - it->first);
-  if (off >= e.n || e.row_k != K || off % (size_t)K != 0) return false;
+  if (e.buf == nullptr || off >= e.n || e.row_k != K || off % (size_t)K != 0) return false;
   if (sp8) *sp8 = e.buf + off * sizeof(float);
   if (wscale) *wscale = e.wscale + off / K;
   return true;
@@ -348,7 +355,11 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   g.a_scale = a.a_scale;
   g.a_mul = a.a_fmt == 1 ? 1.0f : a.a_mul;
   g.a_unmul = a.a_fmt == 1 ? 1.0f : a.a_unmul;
-  g.zero = zero_page();
+  g.zero = sp_zero_page();
+  {  // byte extents of the operands as the DMA addresses them
+    const double lim = 4294967296.0 - 65536.0;
+    g.off32 = ((double)a.M * g.a_rowb + (double)g.a_offb < lim && (double)a.N * a.K * 4.0 < lim) ? 1 : 0;
+  }
   g.tiles_m = pl.tiles_m, g.tiles_n = pl.tiles_n;
   g.cand_s = a.cand_s, g.cand_i = a.cand_i, g.topk = a.topk;
   g.act = a.act;
@@ -359,8 +370,12 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   g.d_kw = make_fastdiv((uint32_t)a.KW);
   g.remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
   g.os = a.os, g.oy = a.oy, g.ox = a.ox, g.OH2 = a.OH2, g.OW2 = a.OW2;
-  if (a.grn_part != nullptr)
+  if (a.grn_part != nullptr) {
     MTGV_CHECK(a.segmax >= (pl.unit_rows - 1) / g.hw + 2, ERR_INVALID, "gemm_sp: segmax %d too small", a.segmax);
+    // the caller sized and will reduce the partial sums for the unit it planned with (gemm_grn_layout)
+    MTGV_CHECK(a.grn_unit_rows == 0 || a.grn_unit_rows == pl.unit_rows, ERR_RUNTIME,
+               "gemm_sp: GRN partials planned for %d-row units, this launch writes %d-row units", a.grn_unit_rows, pl.unit_rows);
+  }
   // f32 A: by DMA and split at the fragment read when the rows are 16-byte aligned, need no range multiplier and a
   // tile's rows span at most 8 images of the per-image multipliers; through registers otherwise
   int amode = a.a_fmt == 1 ? (is_conv(a) ? 2 : 0) : 1;

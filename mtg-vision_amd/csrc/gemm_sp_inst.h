@@ -21,7 +21,8 @@ void sp_launch_one(const SpDev& g, hipStream_t s) {
     const size_t stage = (size_t)SP_WM * SP_WN * 32 * 128 * SP_TN;
     lds = win + ring > stage ? win + ring : stage;
   }
-  static bool attr_done = false;
+  static bool attr_done_dev[MTGV_MAX_DEVICES] = {};  // hipFuncSetAttribute is per device
+  bool& attr_done = attr_done_dev[current_device()];
   auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, SP_NST, AMODE, ACT, EPI>;
   if (!attr_done) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AMODE == 5 ? 160 * 1024 : (int)lds));

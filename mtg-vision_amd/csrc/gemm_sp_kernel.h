@@ -69,6 +69,7 @@ struct SpDev {
   const float* a_scale = nullptr;  // AMODE 1: [M/hw][K]
   float a_mul = 1.0f, a_unmul = 1.0f;  // AMODE 1: power-of-two pre-scale of A (range guard) and its inverse
   const char* zero = nullptr;   // >= 16 zero bytes (K tail / padding taps of the DMA paths)
+  int off32 = 0;                // A and W extents < 4 GB: dense pieces are addressed as uniform base + 32-bit lane offset
   int tiles_m = 0, tiles_n = 0;
   int act = 0;
   // AMODE 2 geometry
@@ -128,6 +129,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   int cslot[PPW], cih0[PPW], ciw0[PPW];  // CONV A pieces: logical slot, first input row / column of the window
   const char* csrc[PPW];             // CONV A pieces, fast form: address of the window's first pixel at this lane's chunk
   const bool conv_fast = AMODE == 2 && g.Cin % (16 * KS) == 0;
+  // Dense pieces (B always, A unless it is gathered) of a launch without a K tail: the DMA's address is a uniform
+  // base (SGPR pair, advanced per stage by scalar adds) plus a 32-bit lane offset fixed for the whole tile - the
+  // saddr form of global_load_lds: no vector arithmetic per piece and half the address bytes per instruction.
+  uint32_t off32[PPW];
+  const bool sfast = g.off32 != 0 && !ktail;
 #pragma unroll
   for (int u = 0; u < PPW; ++u) {
     const int p = wave + NW * u;
@@ -137,6 +143,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
     const int sw = KS == 2 ? (row >> 1) & 7 : (row >> 2) & 3;
     const int slot = (lane % SPR) ^ sw;
     cslot[u] = slot, cih0[u] = 0, ciw0[u] = 0, csrc[u] = nullptr;
+    {
+      const int mm = m0 + row < g.M ? m0 + row : g.M - 1, nn = n0 + row < g.N ? n0 + row : g.N - 1;
+      off32[u] = isA ? (uint32_t)mm * (uint32_t)g.a_rowb + (uint32_t)(slot * 16) : (uint32_t)nn * (uint32_t)wrowb + (uint32_t)(slot * 16);
+    }
     if (isA) {
       int m = m0 + row;
       m = m < g.M ? m : g.M - 1;
@@ -172,40 +182,54 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   // AWIN: [window: win_px pixels x 128 B][weight ring]; otherwise the ring starts at the base
   const int win_px = AWIN ? ((BM + 2 * g.Wd + 2 + 7) & ~7) : 0;
   char* const ring = smem + (AWIN ? win_px * 128 : 0);
+  // one piece the general way: per-lane 64-bit source (conv gather, K tail -> zero page)
+  auto issue_piece = [&](int u, int t, int buf) {
+    const int p = wave + NW * u;
+    const char* s;
+    if (AMODE == 2 && p < PA && conv_fast) {
+      // Cin is a multiple of the stage depth: the whole stage lies inside one tap, so tap, kh, kw and the first
+      // channel are wave-uniform (scalar registers) and a lane only tests its pixel against the padding
+      const uint32_t k0 = (uint32_t)t * (16u * KS);
+      const uint32_t tap = fdiv(k0, g.d_cin);
+      const uint32_t kh = fdiv(tap, g.d_kw);
+      const uint32_t kw = tap - kh * (uint32_t)g.KW;
+      const long tap_off = ((long)kh * g.Wd + kw) * g.a_rowb + (long)(k0 - tap * (uint32_t)g.Cin) * 4;
+      const bool ok = (unsigned)(cih0[u] + (int)kh) < (unsigned)g.H && (unsigned)(ciw0[u] + (int)kw) < (unsigned)g.Wd;
+      s = ok ? csrc[u] + tap_off : g.zero;
+    } else if (AMODE == 2 && p < PA) {
+      // chunk -> (tap, channel); the tap's pixel may fall into the zero padding
+      const int kc = t * 2 * KS + (cslot[u] >> 1);
+      const uint32_t k = (uint32_t)(kc < kchunks ? kc : 0) * 8u;
+      const uint32_t tap = fdiv(k, g.d_cin);
+      const uint32_t c = k - tap * (uint32_t)g.Cin;
+      const uint32_t kh = fdiv(tap, g.d_kw);
+      const uint32_t kw = tap - kh * (uint32_t)g.KW;
+      const int ih = cih0[u] + (int)kh, iw = ciw0[u] + (int)kw;
+      const bool ok = kc < kchunks && ih >= 0 && ih < g.H && iw >= 0 && iw < g.Wd;
+      s = ok ? src[u] + ((long)ih * g.Wd + iw) * g.a_rowb + c * 4 : g.zero;
+    } else {
+      s = src[u] + (long)t * RB;
+      if (t == nk - 1 && tailz[u]) s = g.zero;
+    }
+    // A pieces fill [0, SA), B pieces [SA, STG) (in REG mode the A region is written by ds_write instead)
+    __builtin_amdgcn_global_load_lds((sp_gptr)s, (sp_lptr)(ring + buf * STG + (SA - PA * 1024) + p * 1024), 16, 0, 0);
+  };
   auto issue = [&](int t, int buf) {
+    if (sfast) {  // no K tail, 32-bit extents: dense pieces in the saddr form, straight-line
+      const char* const abase = g.A + g.a_offb + (long)t * RB;  // uniform
+      const char* const wbase = g.W + (long)t * RB;
 #pragma unroll
-    for (int u = 0; u < PPW; ++u) {
-      const int p = wave + NW * u;
-      if (NP % NW == 0 || p < NP) {
-        const char* s;
-        if (AMODE == 2 && p < PA && conv_fast) {
-          // Cin is a multiple of the stage depth: the whole stage lies inside one tap, so tap, kh, kw and the first
-          // channel are wave-uniform (scalar registers) and a lane only tests its pixel against the padding
-          const uint32_t k0 = (uint32_t)t * (16u * KS);
-          const uint32_t tap = fdiv(k0, g.d_cin);
-          const uint32_t kh = fdiv(tap, g.d_kw);
-          const uint32_t kw = tap - kh * (uint32_t)g.KW;
-          const long tap_off = ((long)kh * g.Wd + kw) * g.a_rowb + (long)(k0 - tap * (uint32_t)g.Cin) * 4;
-          const bool ok = (unsigned)(cih0[u] + (int)kh) < (unsigned)g.H && (unsigned)(ciw0[u] + (int)kw) < (unsigned)g.Wd;
-          s = ok ? csrc[u] + tap_off : g.zero;
-        } else if (AMODE == 2 && p < PA) {
-          // chunk -> (tap, channel); the tap's pixel may fall into the zero padding
-          const int kc = t * 2 * KS + (cslot[u] >> 1);
-          const uint32_t k = (uint32_t)(kc < kchunks ? kc : 0) * 8u;
-          const uint32_t tap = fdiv(k, g.d_cin);
-          const uint32_t c = k - tap * (uint32_t)g.Cin;
-          const uint32_t kh = fdiv(tap, g.d_kw);
-          const uint32_t kw = tap - kh * (uint32_t)g.KW;
-          const int ih = cih0[u] + (int)kh, iw = ciw0[u] + (int)kw;
-          const bool ok = kc < kchunks && ih >= 0 && ih < g.H && iw >= 0 && iw < g.Wd;
-          s = ok ? src[u] + ((long)ih * g.Wd + iw) * g.a_rowb + c * 4 : g.zero;
-        } else {
-          s = src[u] + (long)t * RB;
-          if (t == nk - 1 && tailz[u]) s = g.zero;
+      for (int u = 0; u < PPW; ++u) {
+        const int p = wave + NW * u;
+        if (NP % NW == 0 || p < NP) {
+          if (AMODE == 2 && p < PA) issue_piece(u, t, buf);
+          else sp_dma16_saddr(p < PA ? abase : wbase, off32[u], ring + buf * STG + (SA - PA * 1024) + p * 1024);
         }
-        // A pieces fill [0, SA), B pieces [SA, STG) (in REG mode the A region is written by ds_write instead)
-        __builtin_amdgcn_global_load_lds((sp_gptr)s, (sp_lptr)(ring + buf * STG + (SA - PA * 1024) + p * 1024), 16, 0, 0);
       }
+    } else {
+#pragma unroll
+      for (int u = 0; u < PPW; ++u)
+        if (NP % NW == 0 || wave + NW * u < NP) issue_piece(u, t, buf);
     }
     if constexpr (AMODE == 3) {  // the stage's slice of the per-image A multipliers: [8 images from img0][32 k]
       if (wave == NP % NW) {

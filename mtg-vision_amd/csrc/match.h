@@ -16,7 +16,8 @@ class Bank {
   void append(const float* v, int64_t n, bool is_device, hipStream_t s);
   void set_row(int64_t row, const float* v_host, hipStream_t s);
   void get_rows(int64_t row, int64_t n, float* out_host) const;
-  void topk(const float* q, int b, int k, int64_t id_base, int64_t* ids, float* scores, hipStream_t s);
+  // thr: results scoring below it are dropped (id -1, score -inf); -INFINITY keeps everything
+  void topk(const float* q, int b, int k, int64_t id_base, float thr, int64_t* ids, float* scores, hipStream_t s);
 
  private:
   int dim_;
@@ -24,6 +25,7 @@ class Bank {
   DevBuf vecs_, qn_, cand_s_, cand_i_;
 };
 
-void topk_merge_launch_i64(float* cs, const int64_t* ci, int b, int ncand, int k, int64_t* ids, float* scores, hipStream_t s);
+void topk_merge_launch_i64(float* cs, const int64_t* ci, int b, int ncand, int k, float thr, int64_t* ids, float* scores,
+                           hipStream_t s);
 
 }  // namespace mtgv

@@ -11,7 +11,7 @@ namespace mtgv {
 
 template <typename IdT>
 __global__ __launch_bounds__(256) void topk_merge_kernel(float* __restrict__ cs, const IdT* __restrict__ ci, int ncand, int k,
-                                                        long id_base, long* __restrict__ out_ids,
+                                                        long id_base, float thr, long* __restrict__ out_ids,
                                                         float* __restrict__ out_scores) {
   __shared__ float rs[256];
   __shared__ long ri[256];
@@ -40,18 +40,21 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(float* __restrict__ cs,
       __syncthreads();
     }
     if (tid == 0) {
-      const bool ok = rp[0] >= 0;
+      // score_threshold (qdrant.py:83,93): candidates below it are not results - id -1 / score -inf pads, like a
+      // bank with fewer than k rows
+      const bool ok = rp[0] >= 0 && rs[0] >= thr;
       out_scores[(long)b * k + kk] = ok ? rs[0] : -INFINITY;
       out_ids[(long)b * k + kk] = ok ? ri[0] + id_base : -1;
-      if (ok) s[rp[0]] = -INFINITY;  // retire
+      if (rp[0] >= 0) s[rp[0]] = -INFINITY;  // retire
     }
     __syncthreads();
   }
 }
 
-void topk_merge_launch_i64(float* cs, const int64_t* ci, int b, int ncand, int k, int64_t* ids, float* scores, hipStream_t s) {
+void topk_merge_launch_i64(float* cs, const int64_t* ci, int b, int ncand, int k, float thr, int64_t* ids, float* scores,
+                           hipStream_t s) {
   MTGV_CHECK(b > 0 && ncand > 0 && k > 0, ERR_INVALID, "topk_merge: b=%d ncand=%d k=%d", b, ncand, k);
-  hipLaunchKernelGGL((topk_merge_kernel<long>), dim3(b), dim3(256), 0, s, cs, (const long*)ci, ncand, k, 0L, (long*)ids, scores);
+  hipLaunchKernelGGL((topk_merge_kernel<long>), dim3(b), dim3(256), 0, s, cs, (const long*)ci, ncand, k, 0L, thr, (long*)ids, scores);
   HIP_OK(hipGetLastError());
 }
 
@@ -101,7 +104,7 @@ void Bank::get_rows(int64_t row, int64_t n, float* out_host) const {
   HIP_OK(hipMemcpy(out_host, vecs_.p + (size_t)row * dim_, (size_t)n * dim_ * sizeof(float), hipMemcpyDeviceToHost));
 }
 
-void Bank::topk(const float* q, int b, int k, int64_t id_base, int64_t* ids, float* scores, hipStream_t s) {
+void Bank::topk(const float* q, int b, int k, int64_t id_base, float thr, int64_t* ids, float* scores, hipStream_t s) {
   MTGV_CHECK(b > 0 && k > 0 && k <= 65536, ERR_INVALID, "bank: b=%d k=%d (k must be in [1,65536])", b, k);
   MTGV_CHECK(q != nullptr && ids != nullptr && scores != nullptr, ERR_INVALID, "bank: null tensor");
   MTGV_CHECK(size_ > 0, ERR_RUNTIME, "bank is empty");
@@ -125,7 +128,7 @@ void Bank::topk(const float* q, int b, int k, int64_t id_base, int64_t* ids, flo
   g.topk = kt;
   gemm_launch(g, pl, s);
   hipLaunchKernelGGL((topk_merge_kernel<int>), dim3(b), dim3(256), 0, s, cand_s_.p, (const int*)cand_i_.p, (int)ncand, k,
-                     (long)id_base, (long*)ids, scores);
+                     (long)id_base, thr, (long*)ids, scores);
   HIP_OK(hipGetLastError());
 }
 

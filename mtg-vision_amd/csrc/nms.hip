@@ -184,6 +184,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     cls_out[o] = cls;
     keep_idx[o] = a;
   }
+  // slots beyond the kept detections: zeros, so callers may hand in uninitialised output tensors
+  for (int t = nkeep + tid; t < max_det; t += NMS_THREADS) {
+    const long o = (long)img * max_det + t;
+    boxes[o * 4 + 0] = 0.f, boxes[o * 4 + 1] = 0.f, boxes[o * 4 + 2] = 0.f, boxes[o * 4 + 3] = 0.f;
+    conf_out[o] = 0.f;
+    cls_out[o] = 0;
+    keep_idx[o] = 0;
+  }
   if (coef_out != nullptr) {
     // mask coefficients of the kept detections, (max_det, nm) per image, zero beyond n_det
     for (int t = tid; t < max_det * nm; t += NMS_THREADS) {
@@ -212,7 +220,8 @@ void nms_launch(const float* pred, int n, int nc, int nm, int na, float conf, fl
   const size_t lds = (size_t)cap * sizeof(unsigned long long);
   MTGV_CHECK(lds <= 150 * 1024, ERR_INVALID, "nms: %d anchors exceed the LDS sort capacity", na);
   MTGV_CHECK(ws != nullptr && ws_bytes >= nms_workspace_bytes(n, na), ERR_INVALID, "nms: workspace too small");
-  static bool attr_done = false;
+  static bool attr_done_dev[MTGV_MAX_DEVICES] = {};  // hipFuncSetAttribute is per device
+  bool& attr_done = attr_done_dev[current_device()];
   if (!attr_done) {
     HIP_OK(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;

@@ -452,7 +452,8 @@ template <bool LOGITS>
 void launch_quads(const void* src, int n, int h, int w, int scale, const float* boxes, float* quads, int* ok, hipStream_t s) {
   const size_t lds = (size_t)h * (4 * sizeof(int) + 3 * 2 * sizeof(P2) + 3 * 2 * sizeof(double) + 3 * 2 * sizeof(int) + 2 * sizeof(int));
   MTGV_CHECK(lds <= 150 * 1024, ERR_INVALID, "mask_quads: mask height %d exceeds the LDS capacity", h);
-  static bool attr_done = false;
+  static bool attr_done_dev[MTGV_MAX_DEVICES] = {};  // hipFuncSetAttribute is per device
+  bool& attr_done = attr_done_dev[current_device()];
   if (!attr_done) {
     HIP_OK(hipFuncSetAttribute((const void*)mask_quads_kernel<LOGITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;

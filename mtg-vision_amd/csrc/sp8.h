@@ -34,6 +34,16 @@ __device__ __forceinline__ void sp8_split8(const sp_f4 x0, const sp_f4 x1, sp_h8
   lo = sp_h8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
 }
 
+// LDS-DMA in the saddr form: 16 bytes per lane from (uniform 64-bit base in an SGPR pair) + (32-bit lane offset) to
+// (wave-uniform LDS address, through M0) + lane * 16.  hipcc does not select this form for
+// __builtin_amdgcn_global_load_lds once its loop passes have folded the base into a per-lane 64-bit pointer; with it a
+// stage's pieces cost no vector arithmetic (the stage advance is two scalar adds) and the instruction carries half the
+// address bytes.  The compiler does not see the instruction: callers order it by their own s_waitcnt vmcnt(N).
+__device__ __forceinline__ void sp_dma16_saddr(const char* base, uint32_t off, const char* lds) {
+  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)lds;
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+}
+
 // A thread that holds 4 consecutive channels (channel quad c4 of a pixel) turns them into its half of an SP8 chunk
 // and trades halves with the neighbouring lane (c4 ^ 1, the other quad of the same chunk), so every lane ends up with
 // one whole 16-byte piece: even quads the chunk's hi piece, odd quads its lo piece.  Returns the piece; the caller

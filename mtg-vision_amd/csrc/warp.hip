@@ -132,11 +132,46 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
   }
 }
 
+// The K cards of every frame that go on to the crop stage (reference dataflow server.py:139-183):
+// the K highest-confidence detections (NMS output is score-descending) or, where a frame has fewer, fixed pad boxes so
+// that cards per step is constant on synthetic frames.  One thread per card: selected box, its corner quad in the order
+// extract_dewarped matches to [[0,0],[w,0],[w,h],[0,h]] (od_export.py:97-103), and the card's frame index.
+__global__ __launch_bounds__(256) void select_cards_kernel(const int* __restrict__ n_det, const float* __restrict__ boxes,
+                                                          const float* __restrict__ pad, int F, int max_det, int K,
+                                                          float* __restrict__ sel, float* __restrict__ quads,
+                                                          int* __restrict__ frame_idx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F * K) return;
+  const int f = i / K, k = i - f * K;
+  const float* b = (k < n_det[f] && k < max_det) ? boxes + ((long)f * max_det + k) * 4 : pad + k * 4;
+  const float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+  sel[i * 4 + 0] = x1, sel[i * 4 + 1] = y1, sel[i * 4 + 2] = x2, sel[i * 4 + 3] = y2;
+  if (quads != nullptr) {
+    float* q = quads + (long)i * 8;
+    q[0] = x1, q[1] = y1, q[2] = x2, q[3] = y1, q[4] = x2, q[5] = y2, q[6] = x1, q[7] = y2;
+  }
+  frame_idx[i] = f;
+}
+
 }  // namespace mtgv
 
 using namespace mtgv;
 
 extern "C" {
+MTGV_API int mtgv_select_cards(const int32_t* n_det_dev, const float* boxes_dev, const float* pad_boxes_dev, int32_t frames,
+                               int32_t max_det, int32_t k, float* sel_boxes_dev, float* quads_dev, int32_t* frame_idx_dev,
+                               void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(frames >= 0 && max_det > 0 && k > 0, ERR_INVALID, "select_cards: frames=%d max_det=%d k=%d", frames, max_det, k);
+    if (frames == 0) return;
+    MTGV_CHECK(n_det_dev && boxes_dev && pad_boxes_dev && sel_boxes_dev && frame_idx_dev, ERR_INVALID, "select_cards: null argument");
+    hipLaunchKernelGGL(select_cards_kernel, dim3((unsigned)((frames * k + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const int*)n_det_dev, boxes_dev, pad_boxes_dev, frames, max_det, k, sel_boxes_dev, quads_dev,
+                       (int*)frame_idx_dev);
+    HIP_OK(hipGetLastError());
+  });
+}
+
 MTGV_API size_t mtgv_warp_workspace_bytes(int32_t nq) { return nq > 0 ? (size_t)nq * 9 * sizeof(double) : 0; }
 
 MTGV_API int mtgv_warp_quads(const uint8_t* frames_dev, int32_t nf, int32_t fh, int32_t fw, const float* quads_dev,

@@ -428,15 +428,13 @@ class VectorStoreQdrant:
         if len(self._bank) == 0 or k <= 0 or len(vectors) == 0:
             return [[] for _ in range(len(vectors))]
         kk = min(int(k), len(self._bank))
-        ids, scores = self._bank.match(vectors, kk)
+        ids, scores = self._bank.match(vectors, kk, threshold=score_threshold)  # score_threshold applied on the device
         ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
         res = []
         for row_ids, row_scores in zip(ids, scores):
             out = []
             for i, s in zip(row_ids, row_scores):
                 if i < 0:
-                    continue
-                if score_threshold is not None and not (s >= score_threshold):
                     continue
                 pid = self._ids[int(i)]
                 out.append(

@@ -35,6 +35,25 @@ def warp_quads(frames: torch.Tensor, quads: torch.Tensor, frame_idx: torch.Tenso
     return out
 
 
+def select_cards(n_det: torch.Tensor, boxes: torch.Tensor, pad_boxes: torch.Tensor, k: int, want_quads: bool = True):
+    """The K cards per frame that go on to the crop stage, in one library kernel: the K best detections of the padded
+    detector outputs (n_det (F,), boxes (F, max_det, 4), score-descending) or pad_boxes[k] where a frame has fewer.
+    -> (sel_boxes (F*K, 4), quads (F*K, 4, 2) or None, frame_idx (F*K,) int32)."""
+    native.require_gpu()
+    F, md = boxes.shape[0], boxes.shape[1]
+    dev = boxes.device
+    assert n_det.dtype == torch.int32 and boxes.dtype == torch.float32 and tuple(pad_boxes.shape) == (k, 4), f"{tuple(pad_boxes.shape)}"
+    sel = torch.empty((F * k, 4), dtype=torch.float32, device=dev)
+    quads = torch.empty((F * k, 4, 2), dtype=torch.float32, device=dev) if want_quads else None
+    fidx = torch.empty((F * k,), dtype=torch.int32, device=dev)
+    if F == 0:
+        return sel, quads, fidx
+    with torch.cuda.device(dev):
+        native.check(native.lib().mtgv_select_cards(native.ptr(n_det), native.ptr(boxes), native.ptr(pad_boxes), F, md, k, native.ptr(sel),
+                                                    native.ptr(quads), native.ptr(fidx), native.stream()))
+    return sel, quads, fidx
+
+
 def boxes_to_quads(boxes_xyxy: torch.Tensor) -> torch.Tensor:
     """(n, 4) xyxy -> (n, 4, 2) corners in the order extract_dewarped matches to [[0,0],[w,0],[w,h],[0,h]]."""
     x1, y1, x2, y2 = boxes_xyxy.unbind(-1)
@@ -70,8 +89,8 @@ def mask_quads_from_logits(mask_logits: torch.Tensor, boxes_xyxy: torch.Tensor =
     native.require_gpu()
     assert mask_logits.is_cuda and mask_logits.dtype == torch.float32 and mask_logits.ndim == 3
     n, mh, mw = mask_logits.shape
-    quads = torch.zeros((n, 4, 2), dtype=torch.float32, device=mask_logits.device)
-    ok = torch.zeros((n,), dtype=torch.int32, device=mask_logits.device)
+    quads = torch.empty((n, 4, 2), dtype=torch.float32, device=mask_logits.device)  # the kernel writes every row
+    ok = torch.empty((n,), dtype=torch.int32, device=mask_logits.device)
     if n == 0:
         return quads, ok
     if boxes_xyxy is not None:

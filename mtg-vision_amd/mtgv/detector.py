@@ -101,13 +101,14 @@ class Detector:
         n = frames_u8.shape[0]
         assert 0 < n <= self.max_batch, f"batch {n} outside [1, {self.max_batch}]"
         dev = self.device
+        # every element is written by the library (slots / mask rows beyond n_det as zeros): no fill kernels here
         out = {
-            "n_det": torch.zeros((n,), dtype=torch.int32, device=dev),
-            "boxes": torch.zeros((n, md, 4), dtype=torch.float32, device=dev),
-            "conf": torch.zeros((n, md), dtype=torch.float32, device=dev),
-            "cls": torch.zeros((n, md), dtype=torch.int32, device=dev),
-            "keep_idx": torch.zeros((n, md), dtype=torch.int32, device=dev),
-            "mask_logits": torch.zeros((n, mask_rows, S // 4, S // 4), dtype=torch.float32, device=dev) if mask_rows > 0 else None,
+            "n_det": torch.empty((n,), dtype=torch.int32, device=dev),
+            "boxes": torch.empty((n, md, 4), dtype=torch.float32, device=dev),
+            "conf": torch.empty((n, md), dtype=torch.float32, device=dev),
+            "cls": torch.empty((n, md), dtype=torch.int32, device=dev),
+            "keep_idx": torch.empty((n, md), dtype=torch.int32, device=dev),
+            "mask_logits": torch.empty((n, mask_rows, S // 4, S // 4), dtype=torch.float32, device=dev) if mask_rows > 0 else None,
         }
         with torch.cuda.device(dev):
             native.check(

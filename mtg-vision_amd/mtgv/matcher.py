@@ -74,11 +74,13 @@ class Matcher:
     def clear(self):
         native.check(native.lib().mtgv_bank_clear(self._h))
 
-    def match(self, embedding, k: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+    def match(self, embedding, k: int = 1, threshold: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """(D,) or (B,D) raw embeddings -> (ids int64 (B,k), scores float32 (B,k)) on the GPU.
 
         Sorted by cosine score descending, ties by ascending id; id -1 / score -inf pads
-        when the bank holds fewer than k rows."""
+        when the bank holds fewer than k rows.  `threshold` is `score_threshold` of
+        `query_nearby` (mtgvision/qdrant.py:83,93): hits scoring below it are dropped on the
+        device (they become pads)."""
         if isinstance(embedding, np.ndarray) or isinstance(embedding, (list, tuple)):
             embedding = torch.from_numpy(np.ascontiguousarray(np.asarray(embedding, dtype=np.float32)))
         q = embedding.to(self.device, torch.float32)
@@ -93,7 +95,8 @@ class Matcher:
             return ids, scores
         with torch.cuda.device(self.device):
             native.check(
-                native.lib().mtgv_bank_topk(self._h, native.ptr(q), b, int(k), self.id_base, native.ptr(ids), native.ptr(scores), native.stream())
+                native.lib().mtgv_bank_topk(self._h, native.ptr(q), b, int(k), self.id_base, _thr(threshold), native.ptr(ids), native.ptr(scores),
+                                            native.stream())
             )
         return ids, scores
 
@@ -106,7 +109,11 @@ class Matcher:
             pass
 
 
-def merge_topk(cand_scores: torch.Tensor, cand_ids: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def _thr(threshold: Optional[float]) -> float:
+    return float("-inf") if threshold is None else float(threshold)
+
+
+def merge_topk(cand_scores: torch.Tensor, cand_ids: torch.Tensor, k: int, threshold: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Merge (B, ncand) candidate (score, id) pairs - e.g. the all-gathered per-shard top-k -
     into the global top-k with the same (score desc, id asc) order.  Consumes cand_scores."""
     assert cand_scores.is_cuda and cand_ids.is_cuda and cand_scores.shape == cand_ids.shape and cand_scores.ndim == 2
@@ -116,5 +123,5 @@ def merge_topk(cand_scores: torch.Tensor, cand_ids: torch.Tensor, k: int) -> Tup
     ids = torch.empty((b, k), dtype=torch.int64, device=cs.device)
     scores = torch.empty((b, k), dtype=torch.float32, device=cs.device)
     with torch.cuda.device(cs.device):
-        native.check(native.lib().mtgv_topk_merge(native.ptr(cs), native.ptr(ci), b, n, int(k), native.ptr(ids), native.ptr(scores), native.stream()))
+        native.check(native.lib().mtgv_topk_merge(native.ptr(cs), native.ptr(ci), b, n, int(k), _thr(threshold), native.ptr(ids), native.ptr(scores), native.stream()))
     return ids, scores

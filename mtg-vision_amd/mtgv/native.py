@@ -54,6 +54,8 @@ SIGNATURES = {
     "mtgv_device_count": (C.c_int, []),
     "mtgv_set_gemm_precision": (C.c_int, [c_i32]),
     "mtgv_get_gemm_precision": (C.c_int, [C.POINTER(c_i32)]),
+    "mtgv_set_packed_fp32": (C.c_int, [c_i32]),
+    "mtgv_get_packed_fp32": (C.c_int, []),
     "mtgv_profile_gemm": (C.c_int, [c_i32]),
     "mtgv_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64)]),
     "mtgv_profile_gemm_bytes": (C.c_int, [C.POINTER(C.c_double)]),
@@ -74,8 +76,8 @@ SIGNATURES = {
     "mtgv_bank_set_row": (C.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "mtgv_bank_clear": (C.c_int, [c_vp]),
     "mtgv_bank_get_rows": (C.c_int, [c_vp, c_i64, c_i64, c_vp]),
-    "mtgv_bank_topk": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp]),
-    "mtgv_topk_merge": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "mtgv_bank_topk": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp]),
+    "mtgv_topk_merge": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     "mtgv_detector_create": (C.c_int, [C.POINTER(DetectorCfg), C.POINTER(c_vp)]),
     "mtgv_detector_destroy": (None, [c_vp]),
     "mtgv_detector_set_param": (C.c_int, [c_vp, C.c_char_p, c_vp, c_i64]),
@@ -90,6 +92,7 @@ SIGNATURES = {
         [c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_size_t, c_vp],
     ),
     "mtgv_nms_workspace_bytes": (C.c_size_t, [c_i32, c_i32]),
+    "mtgv_select_cards": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mtgv_warp_workspace_bytes": (C.c_size_t, [c_i32]),
     "mtgv_warp_quads": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, C.c_double, c_vp, c_vp, C.c_size_t, c_vp]),
     "mtgv_mask_quads": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
@@ -165,6 +168,16 @@ def set_gemm_precision(name: str) -> None:
     if name not in PRECISIONS:
         raise AssertionError(f"precision {name!r}: expected one of {sorted(PRECISIONS)}")
     check(lib().mtgv_set_gemm_precision(PRECISIONS[name]))
+
+
+def set_packed_fp32(allow: bool) -> None:
+    """Allow / forbid the packed-FP32 build of dwconv7_ln (include/mtgv.h: only while no other stream or process runs
+    f16x3 launches on the same GPU)."""
+    check(lib().mtgv_set_packed_fp32(1 if allow else 0))
+
+
+def get_packed_fp32() -> bool:
+    return bool(lib().mtgv_get_packed_fp32())
 
 
 def get_gemm_precision() -> str:

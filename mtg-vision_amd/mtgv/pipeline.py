@@ -12,7 +12,7 @@ from typing import Callable, Optional
 
 import torch
 
-from .crop import boxes_to_quads, mask_quads_from_logits, warp_quads
+from .crop import mask_quads_from_logits, select_cards, warp_quads
 from .detector import Detector
 from .encoder import Encoder
 from .matcher import Matcher
@@ -38,21 +38,22 @@ class Pipeline:
         self.top_k = int(top_k)
         self.match_fn = match_fn or (lambda z, k: matcher.match(z, k))
         reps = (self.K + _PAD_BOXES.shape[0] - 1) // _PAD_BOXES.shape[0]
-        self._pad = _PAD_BOXES.repeat(reps, 1)[: self.K].to(detector.device)
+        self._pad = _PAD_BOXES.repeat(reps, 1)[: self.K].to(detector.device).contiguous()
 
     def _embed_match(self, frames_u8: torch.Tensor, det):
         F, K = frames_u8.shape[0], self.K
-        # the K highest-confidence detections per frame (NMS output is score-descending); pad if fewer
-        have = torch.arange(K, device=frames_u8.device)[None, :] < det["n_det"][:, None]
-        boxes = torch.where(have[..., None], det["boxes"][:, :K], self._pad[None].expand(F, K, 4))
-        quads = boxes_to_quads(boxes.reshape(F * K, 4))
-        if self.quad_source == "mask":
-            # masks of the K best detections (logits are zero outside a detection's box): interpolated to frame
-            # resolution, thresholded and fitted inside one kernel
-            mq, ok = mask_quads_from_logits(det["mask_logits"][:, :K].reshape(F * K, *det["mask_logits"].shape[-2:]), boxes.reshape(F * K, 4))
-            use = (ok.view(F, K) > 0) & have  # no detection / empty mask: keep the box (or pad) quad
-            quads = torch.where(use.reshape(F * K, 1, 1), mq, quads)
-        frame_idx = torch.arange(F, device=frames_u8.device, dtype=torch.int32).repeat_interleave(K)
+        # the K highest-confidence detections per frame (NMS output is score-descending), pad boxes where a frame has
+        # fewer; every step of the glue is a library kernel (no PyTorch arithmetic on the streams of the step)
+        want_mask = self.quad_source == "mask"
+        sel, quads, frame_idx = select_cards(det["n_det"], det["boxes"], self._pad, K, want_quads=not want_mask)
+        if want_mask:
+            # masks of the K best detections (logits are zero outside a detection's box and in rows beyond n_det):
+            # interpolated to frame resolution, thresholded and fitted inside one kernel; an empty mask - no detection
+            # in that slot, or nothing above threshold - falls back to the slot's box inside the kernel
+            ml = det["mask_logits"]
+            assert ml.shape[1] == K, f"mask rows {ml.shape[1]} != cards per frame {K}"
+            quads, _ = mask_quads_from_logits(ml.view(F * K, *ml.shape[-2:]), sel)
+        boxes = sel.view(F, K, 4)
         crops = warp_quads(frames_u8, quads, frame_idx, self.encoder.cfg.image_hw, 0.05)
         z = self.encoder.encode(crops)
         ids, scores = self.match_fn(z, self.top_k)
@@ -70,8 +71,10 @@ class Pipeline:
     def overlap_enabled() -> bool:
         """Two-stream overlap is opt-in (MTGV_OVERLAP=on): while the split-precision GEMMs of one stream run, kernels of
         OTHER libraries that use packed-FP32 VALU instructions on another stream of the same GPU have been seen to lose
-        lanes.  This library is built without those instructions and tests/test_gpu_overlap.py
-        guards its own overlapped path; an application that runs foreign kernels beside it keeps the default."""
+        lanes.  This library is built without those instructions, both streams of `run_many` launch
+        library kernels only (output tensors are torch.empty, the glue between the stages is mtgv_select_cards) and
+        tests/test_gpu_overlap.py guards the combination; an application that runs foreign kernels beside it keeps the
+        default."""
         return os.environ.get("MTGV_OVERLAP", "off") == "on"
 
     def run_many(self, batches, flip_rgb: bool = True):

@@ -116,14 +116,16 @@ def test_detect_matches_oracle(det_setup):
         common = np.intersect1d(got_idx, ref_idx)
         flips = max(k, len(ref_idx)) - len(common)
         print(f"frame {i}: kept {k} (oracle {len(ref_idx)}), threshold flips {flips}")
-        assert k > 10 and flips <= max(3, k // 50)
+        # observed on MI355X with these seeds: 0 flips on every frame; one keep/suppress decision at a threshold is the
+        # most fp32 summation order can explain on a frame, so that is what the test allows
+        assert k > 10 and flips <= 1
         gi = {a: j for j, a in enumerate(got_idx)}
         ri = {a: j for j, a in enumerate(ref_idx)}
         gsel = np.asarray([gi[a] for a in common]); rsel = np.asarray([ri[a] for a in common])
         # order: both score-descending; anchors whose scores differ by less than the forward noise may swap
         assert (np.diff(o["conf"][i, :k]) <= 0).all()
         moved = np.abs(gsel - rsel)
-        assert moved.max() <= 2 + flips
+        assert moved.max() <= 1 + flips  # observed: one adjacent swap of two near-equal scores
         np.testing.assert_array_equal(o["cls"][i, :k][gsel], ref["cls"][rsel])
         assert np.abs(o["boxes"][i, :k][gsel] - ref["boxes"][rsel]).max() < 640 * 1e-4
         assert np.abs(o["conf"][i, :k][gsel] - ref["conf"][rsel]).max() < 1e-4

@@ -37,6 +37,23 @@ def test_two_ranks_sharded_bench_runs():
     assert res["roofline"]["achieved"] > 0  # the roofline leg contains a collective: it must run on every rank
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain shell (no torch.distributed.run in front, RANK unset): the parent starts
+    the ranks as a child process and relays rank 0's line"""
+    env = dict(os.environ, MTGV_SHARE_GPU="1", MTGV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4",
+           "--bank", "20000", "--encoder", "cnvnxt2ae_nano", "--no-f32-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0
+    assert res["config"]["rccl_world"] == 2 and res["config"]["dist_backend"] == "gloo"
+
+
 def test_sharded_equals_replicated_ids():
     """same queries against a replicated bank and against 3 row shards merged: identical ids and scores"""
     import torch

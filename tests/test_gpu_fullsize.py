@@ -83,8 +83,10 @@ def test_detector_batch32_equals_single_frames():
         assert ((out["cls"][i, :n] >= 0) & (out["cls"][i, :n] < cfg.nc)).all()
 
 
-def test_pipeline_full_step_properties():
-    """one bench-sized step: every card gets an id in range, crops are uint8 192x128, scores are cosines"""
+@pytest.mark.parametrize("quad_source", ["mask", "box"])
+def test_pipeline_full_step_properties(quad_source):
+    """one bench-sized step (both crop dataflows; "mask" is the bench default): every card gets an id in range, crops are
+    uint8 192x128, scores are cosines; mask quads and their crops equal the oracle's on the GPU's own masks"""
     from mtgv import spec
     from mtgv.detector import Detector
     from mtgv.encoder import Encoder
@@ -96,9 +98,22 @@ def test_pipeline_full_step_properties():
     g = torch.Generator(device="cuda").manual_seed(2)
     m.add(torch.randn((100_000, 768), generator=g, device="cuda"))
     pipe = Pipeline(Detector(det_cfg, spec.random_detector_state(det_cfg, 3), max_batch=32),
-                    Encoder(enc_cfg, spec.random_encoder_state(enc_cfg, 1), max_batch=256), m, 8, 3)
+                    Encoder(enc_cfg, spec.random_encoder_state(enc_cfg, 1), max_batch=256), m, 8, 3, quad_source=quad_source)
     frames = torch.randint(0, 256, (32, 640, 640, 3), generator=g, device="cuda", dtype=torch.uint8)
     o = pipe.run(frames)
+    if quad_source == "mask":
+        from mtgv.detector import binarize_masks
+        from oracle import pipeline_ref, quad_ref, warp_ref
+
+        sub = slice(0, 64)  # the first 8 frames' cards against the CPU oracle (python loops: bounded)
+        boxes = o["boxes"].reshape(256, 4).cpu().numpy()
+        masks = binarize_masks(o["det"]["mask_logits"][:, :8].reshape(256, 160, 160)[sub]).cpu().numpy()
+        rq, rok = quad_ref.mask_quads(masks, boxes[sub])
+        quads = np.where((rok > 0)[:, None, None], rq, pipeline_ref.boxes_to_quads(boxes[sub]))
+        fr = frames[:8].cpu().numpy()
+        crops = np.stack([warp_ref.warp_quad(fr[i // 8], quads[i], enc_cfg.image_hw, 0.05) for i in range(64)])
+        np.testing.assert_array_equal(o["crops"][sub].cpu().numpy(), crops)
+        assert (rok > 0).sum() > 16
     assert o["ids"].shape == (32, 8, 3) and o["crops"].shape == (256, 192, 128, 3) and o["crops"].dtype == torch.uint8
     assert ((o["ids"] >= 0) & (o["ids"] < 100_000)).all()
     s = o["scores"]

@@ -85,6 +85,84 @@ def test_full_size_properties():
     assert (ms == sc).all()
 
 
+def test_full_size_vs_oracle_fp64():
+    """BASELINE size through the fused top-k epilogue of the LDS-DMA kernel (256 queries >= 128, 100k x 768): ids against
+    the fp64 brute-force oracle (blockwise over the bank, a few seconds on the host), exact outside near-ties."""
+    from mtgv.matcher import Matcher
+    from oracle import match_ref as M
+
+    rng = np.random.default_rng(12)
+    bank = rng.standard_normal((100_000, 768), dtype=np.float32)
+    q = rng.standard_normal((256, 768), dtype=np.float32) * 2
+    # a planted near-neighbour for half of the queries, so the winners are not all at the noise floor
+    pick = rng.integers(0, 100_000, 128)
+    q[:128] = bank[pick] * 1.5 + 0.3 * rng.standard_normal((128, 768), dtype=np.float32)
+    m = Matcher(768, capacity=100_000)
+    m.add(torch.from_numpy(bank).cuda())
+    k = 3
+    ids, sc = m.match(torch.from_numpy(q).cuda(), k)
+    ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
+    qn = M.l2_normalize(q.astype(np.float64))
+    best_s = np.full((256, k + 1), -np.inf)
+    best_i = np.full((256, k + 1), -1, np.int64)
+    for b0 in range(0, 100_000, 12_500):  # blockwise fp64 scores, running top k+1 (score desc, id asc)
+        s = qn @ M.l2_normalize(bank[b0 : b0 + 12_500].astype(np.float64)).T
+        cs = np.concatenate([best_s, s], 1)
+        ci = np.concatenate([best_i, np.broadcast_to(np.arange(b0, b0 + s.shape[1]), s.shape)], 1)
+        order = np.lexsort((ci, -cs), axis=1)[:, : k + 1]
+        best_s, best_i = np.take_along_axis(cs, order, 1), np.take_along_axis(ci, order, 1)
+    margin = (best_s[:, :-1] - best_s[:, 1:]).min(1)
+    safe = margin > 1e-6
+    assert safe.mean() > 0.95
+    assert (ids[safe] == best_i[safe, :k]).all(), "top-k ids differ from the fp64 oracle outside near-ties"
+    assert (ids[:128, 0] == pick).all()
+    assert np.abs(sc - best_s[:, :k]).max() < 2e-6
+
+
+def test_exact_ties_in_the_fused_epilogue():
+    """>= 128 queries go through the fused per-wave top-k epilogue (EPI 16): duplicated bank rows that sit in different
+    wave column ranges (96 columns) and different 192-column tiles must come back in ascending id order."""
+    from mtgv.matcher import Matcher
+
+    rng = np.random.default_rng(5)
+    d, n, b = 64, 1000, 160
+    bank = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((b, d), dtype=np.float32)
+    dup = [3, 97, 200, 385, 700]  # wave ranges 0 / 1 of tile 0, tiles 1, 2, 3
+    for j, r in enumerate(dup):
+        bank[r] = q[7] * (1.0 + j)  # same direction: identical cosine after normalisation
+    m = Matcher(d, capacity=n)
+    m.add(bank)
+    ids, sc = m.match(torch.from_numpy(q).cuda(), 6)
+    assert ids[7, :5].tolist() == dup, ids[7].tolist()
+    assert (sc[7, :5] == sc[7, 0]).all() and sc[7, 5] < sc[7, 0]
+    # a threshold above every other score keeps exactly the duplicates (applied on the device)
+    ids_t, sc_t = m.match(torch.from_numpy(q[7:8]).cuda().repeat(130, 1), 6, threshold=float(sc[7, 0]) - 1e-3)
+    assert ids_t[0].tolist() == dup + [-1] and torch.isinf(sc_t[0, 5])
+    assert (ids_t == ids_t[0]).all()
+
+
+def test_score_threshold_small_batch():
+    from mtgv.matcher import Matcher, merge_topk
+
+    d = 8
+    e0 = np.eye(d, dtype=np.float32)[0]
+    e1 = np.eye(d, dtype=np.float32)[1]
+    bank = np.stack([e0, (e0 + e1) / np.sqrt(2), e1, -e0]).astype(np.float32)
+    m = Matcher(d, capacity=4)
+    m.add(bank)
+    ids, sc = m.match(e0, 4, threshold=0.5)
+    assert ids[0].tolist() == [0, 1, -1, -1] and torch.isinf(sc[0, 2:]).all()
+    ids, sc = m.match(e0, 4, threshold=None)
+    assert ids[0].tolist() == [0, 1, 2, 3]
+    cs = torch.tensor([[0.9, 0.2, 0.7]], device="cuda")
+    ci = torch.tensor([[5, 6, 7]], device="cuda")
+    mi, ms = merge_topk(cs, ci, 3, threshold=0.6)
+    assert mi[0].tolist() == [5, 7, -1]
+    with pytest.raises(AssertionError):
+        m.match(e0, 1, threshold=float("nan"))
+
+
 def test_errors():
     from mtgv.matcher import Matcher
 

@@ -80,3 +80,40 @@ def test_yolo11_batch_equals_single_frames(det11):
         det.forward(fr[i : i + 1], True, 0)
         p1, q1 = det.raw_outputs(1)
         assert torch.equal(p1[0], pred_b[i]) and torch.equal(q1[0], protos_b[i])
+
+
+def test_yolo11_batch32_forward_and_nms():
+    """BASELINE config 3's batch (32 frames) on the trained detector family: raw head + prototypes within 1e-4 of the CPU
+    oracle, NMS bit-exact on the predictions it was given, for every frame of the batch"""
+    from mtgv import spec
+    from mtgv.detector import Detector
+    from oracle import detector_ref as D
+
+    cfg = spec.yolo11_config()
+    sd = spec.random_detector_state(cfg, 3, cls_bias=-0.9)
+    frames = np.random.default_rng(14).integers(0, 256, (32, 640, 640, 3), dtype=np.uint8)
+    det = Detector(cfg, sd, max_batch=32)
+    out = det.forward(torch.from_numpy(frames).cuda(), True, 8)
+    pred, protos = det.raw_outputs(32)
+    pred, protos = pred.cpu().numpy(), protos.cpu().numpy()
+    ref_pred, ref_protos = D.forward(sd, cfg, frames)
+    ref_pred, ref_protos = np.asarray(ref_pred), np.asarray(ref_protos)
+    nc = cfg.nc
+    assert np.abs(pred[:, :4] - ref_pred[:, :4]).max() < 640 * 1e-4
+    assert np.abs(pred[:, 4:] - ref_pred[:, 4:]).max() < 1e-4
+    assert np.abs(protos - ref_protos).max() < 1e-4
+    o = {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items()}
+    total = 0
+    for i in range(32):
+        k = int(o["n_det"][i])
+        total += k
+        same_in = D.nms_single(pred[i], nc, cfg.conf, cfg.iou, cfg.max_det)
+        np.testing.assert_array_equal(o["keep_idx"][i, :k], same_in["keep_idx"])
+        np.testing.assert_array_equal(o["cls"][i, :k], same_in["cls"])
+        np.testing.assert_array_equal(o["boxes"][i, :k], same_in["boxes"])
+        assert (o["boxes"][i, k:] == 0).all() and (o["keep_idx"][i, k:] == 0).all()  # padding written by the kernel
+        kk = min(k, 8)
+        ml = D.mask_logits(pred[i], protos[i], {key: v[:kk] for key, v in same_in.items()}, nc, cfg.imgsz)
+        assert np.abs(o["mask_logits"][i, :kk] - ml).max() < 1e-4
+        assert (o["mask_logits"][i, kk:] == 0).all()
+    assert total > 100
