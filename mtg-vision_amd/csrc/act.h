@@ -47,15 +47,24 @@ __device__ __forceinline__ float act_gelu(float x) {
 }
 
 // nn.Mish = x * tanh(softplus(x)), softplus threshold 20 - mtgvision/models/convnextv2ae.py:17-18
-// Evaluated as x * n / (n + 2) with n = e^x (e^x + 2): tanh(log(1 + e^x)) = ((1+e^x)^2 - 1) / ((1+e^x)^2 + 1)
-// exactly, so one exp and one reciprocal replace exp + log1p + tanh; no cancellation anywhere, same
-// 20.0 cut-over as torch's softplus.
+// tanh(log(1 + e^x)) = ((1+e^x)^2 - 1) / ((1+e^x)^2 + 1) = 1 - 2 / d with d = e^x (e^x + 2) + 2, so
+//   mish(x) = x - 2 x / d:   one exp, one reciprocal, no log1p / tanh, and no clamp: for large x, e^x and d overflow to
+// +inf, 1/d = 0 and the result is x exactly - what torch's softplus threshold gives (tanh(x) = 1 in f32 beyond 20); for
+// very negative x, d -> 2 and the result -> 0.  Absolute error <= ~1.2e-7 |x| (the subtraction's rounding), i.e. at the
+// f32 level of the GEMM that produced x.  scale: an optional factor applied to the result (GRN multiplier in the fused
+// MLP kernel), folded into the two terms.
+__device__ __forceinline__ float act_mish_scaled(float x, float scale) {
+#pragma clang fp contract(off)
+  const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+  const float d = __builtin_fmaf(e, e + 2.0f, 2.0f);
+  const float xs = x * scale;
+  return __builtin_fmaf(xs * fast_rcp(d), -2.0f, xs);
+}
 __device__ __forceinline__ float act_mish(float x) {
 #pragma clang fp contract(off)
-  // beyond the cut-over n = e^40 and n + 2 == n in f32: the quotient is 1 to the last ulp, so the clamp alone gives x
-  const float e = fast_exp(fminf(x, 20.0f));
-  const float n = e * (e + 2.0f);
-  return x * (n * fast_rcp(n + 2.0f));
+  const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+  const float d = __builtin_fmaf(e, e + 2.0f, 2.0f);
+  return __builtin_fmaf(x * fast_rcp(d), -2.0f, x);
 }
 
 // SiLU of the YOLO Conv block (ultralytics Conv.default_act; call site od_export.py:150)

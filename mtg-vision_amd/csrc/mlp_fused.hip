@@ -1,7 +1,9 @@
 // Fused ConvNeXt-V2 MLP: launch side (kernels in mlp_fused_kernel.h).
 #include "mlp_fused.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 #include "gemm_sp.h"
 #include "mlp_fused_kernel.h"
@@ -18,8 +20,16 @@ template <int C16, int ACT, int PASS>
 void launch_pass(const MlpDev& g, hipStream_t s) {
   constexpr int C = 16 * C16, KB = (C16 + 1) / 2;
   constexpr int NV = PASS == 2 ? 4 : 2;
-  constexpr size_t lds = (size_t)((NV * 4 * C * 4 + (PASS == 2 ? 2 * C * 4 : 0) + 1023) / 1024) * 1024 + (size_t)3 * KB * 4096;
-  static_assert(lds <= 64 * 1024, "two blocks per CU without an opt-in");
+  constexpr size_t lds = (size_t)((NV * 4 * C * 4 + (PASS == 2 ? 2 * C * 4 : 0) + 1023) / 1024) * 1024 + (size_t)(PASS == 2 ? 6 : 3) * KB * 4096;
+  static_assert(lds <= 80 * 1024, "two blocks per CU");
+  if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit: opt in once per device
+    static bool attr_done_dev[MTGV_MAX_DEVICES] = {};
+    bool& attr_done = attr_done_dev[current_device()];
+    if (!attr_done) {
+      HIP_OK(hipFuncSetAttribute((const void*)mlp_fused_kernel<C16, ACT, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done = true;
+    }
+  }
   hipLaunchKernelGGL((mlp_fused_kernel<C16, ACT, PASS>), dim3((unsigned)ceil_div(g.M, 128)), dim3(256), lds, s, g);
   HIP_OK(hipGetLastError());
 }
@@ -76,8 +86,29 @@ void mlp_fused_launch(const MlpArgs& a, hipStream_t s) {
   GemmArgs r2;
   r2.M = M, r2.N = a.C, r2.K = H4, r2.a_scale = a.scale, r2.res = a.res;
   gemm_profile_begin(r2, s, 2, tiles * wbytes, 4.0 * (3.0 * (double)M * a.C + 2.0 * H4 * a.C));
+  // tuning aid: MTGV_MLP_STAMPS=<file> appends [M, C, tiles] + per-tile stamps of every pass-2 launch (synchronises)
+  static const char* stamp_path = getenv("MTGV_MLP_STAMPS");
+  long* sbuf = nullptr;
+  const int ntiles = ceil_div(M, 128);
+  if (stamp_path != nullptr && *stamp_path) {
+    HIP_OK(hipMalloc(&sbuf, (size_t)ntiles * 8 * sizeof(long)));
+    HIP_OK(hipMemsetAsync(sbuf, 0, (size_t)ntiles * 8 * sizeof(long), s));
+    g.stamps = sbuf;
+  }
   launch_any<2>(g, a.C, a.act, s);
   gemm_profile_end(s);
+  if (sbuf != nullptr) {
+    std::vector<long> host((size_t)ntiles * 8);
+    HIP_OK(hipStreamSynchronize(s));
+    HIP_OK(hipMemcpy(host.data(), sbuf, host.size() * sizeof(long), hipMemcpyDeviceToHost));
+    HIP_OK(hipFree(sbuf));
+    if (FILE* f = fopen(stamp_path, "ab")) {
+      const long hdr[3] = {M, a.C, ntiles};
+      fwrite(hdr, sizeof(long), 3, f);
+      fwrite(host.data(), sizeof(long), host.size(), f);
+      fclose(f);
+    }
+  }
 }
 
 }  // namespace mtgv

@@ -16,7 +16,8 @@
 // One block = 4 waves x 32 rows.  A wave keeps its 32 x C slice of x (SP8: sp8.h) in registers for the whole tile, as
 // MFMA fragments; the weights stream through a ring of three LDS slots by LDS-DMA (global_load_lds_dwordx4), one slot
 // = the W1 rows of one hidden chunk ([32][C], as C/32 sub-blocks of [32][128 B]) or the W2 columns of one chunk
-// ([C][32 k] = [C][128 B]); slots are consumed in the order W1(0), W2(0), W1(1), W2(1), ... with two slots in flight.
+// ([C][32 k] = [C][128 B]); slots are consumed in the order W1(0), W2(0), W1(1), W2(1), ... with two (PASS 1) or four
+// (PASS 2: a ring of six) slots in flight and one s_barrier per chunk.
 // Per-channel vectors (row scales of W1, b1, and the GRN multipliers of the tile's <= 2 images) are staged once per tile.
 //
 // MFMA orientation.  PASS 2 uses "m on lanes" for both GEMMs: v_mfma_f32_32x32x16_f16(W fragment, x fragment) leaves
@@ -29,6 +30,8 @@
 //
 // Products: lo*hi + hi*lo + hi*hi per k16 step, k ascending; results do not depend on the batch or the tile.
 #pragma once
+#include <type_traits>
+
 #include "act.h"
 #include "sp8.h"
 
@@ -51,6 +54,7 @@ struct MlpDev {
   float* Out = nullptr;         // [M][C] f32
   float* part = nullptr;        // PASS 1: [M / 32][4C]
   const char* zero = nullptr;   // >= 16 zero bytes
+  long* stamps = nullptr;       // tuning aid (MTGV_MLP_STAMPS): [tile][8] clock stamps and wait sums of wave 0
   int M = 0, hw = 1, n_img = 1;
   FastDiv d_hw;
 };
@@ -67,14 +71,17 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpDev g) {
   constexpr int VB = H4 * 4;                  // bytes per vector
   constexpr int XB = PASS == 2 ? 2 * C * 4 : 0;  // PASS 2: ws2 and b2 (C floats each) behind them
   constexpr int EXP = (NV * VB + XB + 1023) / 1024, EXB = EXP * 1024;
-  constexpr int NS = PASS == 2 ? 2 * NCH : NCH;  // slots in consumption order
+  constexpr int NS = PASS == 2 ? 2 * NCH : NCH;  // weight slots in consumption order
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  char* const ring = smem + EXB;
+  char* const ring = smem + EXB;  // PASS 1: 3 slots, PASS 2: 6
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * BM;
+  const bool stamp = g.stamps != nullptr;
+  const long st0 = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
+  long st1 = 0, wa = 0, wb = 0;
   const int mrow = m0 + wave * 32 + r;
   const int mc = mrow < g.M ? mrow : g.M - 1;
   const bool wave_active = m0 + wave * 32 < g.M;
@@ -137,41 +144,68 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpDev g) {
       for (int u = 0; u < PPW; ++u) sp_dma16_saddr(base, w2_off[u], dst + u * 4096);
     }
   };
-  issue(0, 0);
-  if (NS > 1) issue(1, 1);
-
   const unsigned swr = (unsigned)(r >> 1) & 7u;
   const unsigned frag = (unsigned)r * 128u;
-  auto wait_slot = [&](bool last) {  // the oldest outstanding slot has landed (this wave's pieces); the youngest may fly
-    if (last) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
-  };
   auto activate = [&](float x) -> float {
     if constexpr (ACT == ACT_GELU) return act_gelu(x);
     else return act_mish(x);
   };
-
-  if constexpr (PASS == 1) {
-    // lane = hidden channel 32 j + r of rows 8 gq + 4 h + e
-    const long unit = (long)(m0 >> 5) + wave;
-    int rb = 0;
-    for (int j = 0; j < NCH; ++j) {
-      wait_slot(j + 1 >= NS);
-      __builtin_amdgcn_s_barrier();
-      if (j + 2 < NS) issue(j + 2, rb == 0 ? 2 : rb - 1);
-      const char* const sb = ring + rb * SLOT;
-      mlp_f16v acc;
+  // this wave's pieces of every slot but the N youngest have landed
+  auto wait_but = [&](int slots_in_flight) {
+    if (slots_in_flight >= 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * PPW) : "memory");
+    else if (slots_in_flight == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+    else if (slots_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  };
+  // GEMM1 of one hidden chunk out of a W1 slot.  XFIRST: x fragment as the first operand (hidden channel on lanes).
+  // Every fragment of the chunk is requested before the first MFMA (the registers are there: two waves per SIMD), so
+  // the matrix pipe does not wait on an LDS round trip per k16 step.
+  auto gemm1 = [&](const char* sb, auto XFIRST_T) -> mlp_f16v {
+    constexpr bool XFIRST = decltype(XFIRST_T)::value;
+    sp_h8 wh[C16], wl[C16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int s = 0; s < C16; ++s) {
+      const char* const p = sb + (s >> 1) * 4096 + frag;
+      wh[s] = *reinterpret_cast<const sp_h8*>(p + (((4 * (s & 1) + 2 * h + 0) ^ swr) << 4));
+      wl[s] = *reinterpret_cast<const sp_h8*>(p + (((4 * (s & 1) + 2 * h + 1) ^ swr) << 4));
+    }
+    mlp_f16v acc;
 #pragma unroll
-      for (int s = 0; s < C16; ++s) {
-        const char* const p = sb + (s >> 1) * 4096 + frag;
-        const sp_h8 wh = *reinterpret_cast<const sp_h8*>(p + (((4 * (s & 1) + 2 * h + 0) ^ swr) << 4));
-        const sp_h8 wl = *reinterpret_cast<const sp_h8*>(p + (((4 * (s & 1) + 2 * h + 1) ^ swr) << 4));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s], wl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[s], wh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s], wh, acc, 0, 0, 0);
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < C16; ++s) {
+      if constexpr (XFIRST) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s], wl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[s], wh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s], wh[s], acc, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh[s], acc, 0, 0, 0);
       }
+    }
+    return acc;
+  };
+
+  // Both passes are software-pipelined over the hidden chunks: an iteration holds the matrix work of chunk j + 1
+  // (GEMM1) next to the vector work of chunk j (activation, statistics or split) in one basic block, so every wave
+  // feeds the matrix pipe and the vector ALU at once instead of in alternating bursts.
+  if constexpr (PASS == 1) {
+    // slots: W1(0), W1(1), ...; ring of 3, two slots in flight.  lane = hidden channel 32 j + r of rows 8 gq + 4 h + e
+    constexpr int NR = 3;
+    issue(0, 0);
+    if (NS > 1) issue(1, 1);
+    if (NS > 2) issue(2, 2);
+    wait_but(NS > 2 ? 2 : NS - 1);
+    __builtin_amdgcn_s_barrier();
+    mlp_f16v acc = gemm1(ring, std::true_type{});
+    const long unit = (long)(m0 >> 5) + wave;
+    for (int j = 0; j < NCH; ++j) {
+      wait_but(j + 2 < NS ? 1 : 0);
+      __builtin_amdgcn_s_barrier();
+      if (j + 3 < NS) issue(j + 3, j % NR);
+      // (the last iteration repeats its own chunk and drops the result: one basic block per iteration)
+      const mlp_f16v nxt = gemm1(ring + ((j + 1 < NCH ? j + 1 : j) % NR) * SLOT, std::true_type{});
       const float ws = *reinterpret_cast<const float*>(smem + (32 * j + r) * 4);
       const float bs = *reinterpret_cast<const float*>(smem + VB + (32 * j + r) * 4);
       float ssq = 0.f;
@@ -182,9 +216,19 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpDev g) {
       }
       ssq += __shfl_xor(ssq, 32);
       if (h == 0 && wave_active) g.part[unit * H4 + 32 * j + r] = ssq;
-      rb = rb == 2 ? 0 : rb + 1;
+#pragma unroll
+      for (int i = 0; i < 3 * C16; ++i) {  // one MFMA, then its share of the chunk's vector work
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, 10, 0);
+      }
+      acc = nxt;
     }
   } else {
+    // slots: W1(0), then W2(j), W1(j + 1) per chunk; ring of 6, four slots (two iterations) in flight
+    constexpr int NR = 6;
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl)
+      if (sl < NS) issue(sl, sl);
     mlp_f16v acc2[KB];
 #pragma unroll
     for (int nb = 0; nb < KB; ++nb)
@@ -194,61 +238,71 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpDev g) {
     const unsigned sel = (unsigned)((int)fdiv((uint32_t)mc, g.d_hw) - img0);
     const char* const ex = smem + h * 16;
     const char* const ex_s = ex + (2 + (sel > 1 ? 1 : sel)) * VB;
-    int rb = 0;
+    static_assert(NS >= 5, "the prologue issues five slots");
+    wait_but(4);
+    __builtin_amdgcn_s_barrier();
+    if (stamp) st1 = (long)__builtin_amdgcn_s_memtime();
+    mlp_f16v acc = gemm1(ring, std::false_type{});
     for (int j = 0; j < NCH; ++j) {
-      // ---- phase A: GEMM1 of chunk j out of slot 2 j ----
-      wait_slot(false);
+      // slots 2 j + 1 (W2 of chunk j) and 2 j + 2 (W1 of chunk j + 1) have landed; 2 j + 3 and 2 j + 4 may still fly
+      const long ta = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
+      wait_but(j + 3 <= NCH ? 2 : (j + 2 <= NCH ? 1 : 0));
       __builtin_amdgcn_s_barrier();
-      if (2 * j + 2 < NS) issue(2 * j + 2, rb == 0 ? 2 : rb - 1);
-      mlp_f16v acc;
-      {
-        const char* const sb = ring + rb * SLOT;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-        for (int s = 0; s < C16; ++s) {
-          const char* const p = sb + (s >> 1) * 4096 + frag;
-          const sp_h8 wh = *reinterpret_cast<const sp_h8*>(p + (((4 * (s & 1) + 2 * h + 0) ^ swr) << 4));
-          const sp_h8 wl = *reinterpret_cast<const sp_h8*>(p + (((4 * (s & 1) + 2 * h + 1) ^ swr) << 4));
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[s], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[s], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[s], acc, 0, 0, 0);
-        }
-      }
-      rb = rb == 2 ? 0 : rb + 1;
-      // ---- phase B: activation, GRN multiplier, split; GEMM2 of chunk j out of slot 2 j + 1 ----
-      wait_slot(2 * j + 2 >= NS);
-      __builtin_amdgcn_s_barrier();
-      if (2 * j + 3 < NS) issue(2 * j + 3, rb == 0 ? 2 : rb - 1);
-      sp_f4 hv[4];
+      if (stamp) wa += (long)__builtin_amdgcn_s_memtime() - ta;
+      if (2 * j + 5 < NS) issue(2 * j + 5, (2 * j + 5) % NR);
+      if (2 * j + 6 < NS) issue(2 * j + 6, (2 * j + 6) % NR);
+      // GEMM1 of the next chunk; the last iteration repeats its own chunk (slot 2 j is still in the ring) and drops the
+      // result, so that the iteration stays one basic block the scheduler can interleave
+      const mlp_f16v nxt = gemm1(ring + ((j + 1 < NCH ? 2 * j + 2 : 2 * j) % NR) * SLOT, std::false_type{});
+      // the chunk's per-channel constants and the W2 fragments of both k16 steps, requested up front
+      sp_f4 cw[4], cb[4], cs[4];
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int eo = (32 * j + 8 * gq) * 4;
-        const sp_f4 ws = *reinterpret_cast<const sp_f4*>(ex + eo);
-        const sp_f4 bs = *reinterpret_cast<const sp_f4*>(ex + VB + eo);
-        const sp_f4 sc = *reinterpret_cast<const sp_f4*>(ex_s + eo);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hv[gq][e] = activate(__builtin_fmaf(acc[4 * gq + e], ws[e], bs[e])) * sc[e];
+        cw[gq] = *reinterpret_cast<const sp_f4*>(ex + eo);
+        cb[gq] = *reinterpret_cast<const sp_f4*>(ex + VB + eo);
+        cs[gq] = *reinterpret_cast<const sp_f4*>(ex_s + eo);
       }
-      {
-        const char* const sb = ring + rb * SLOT;
+      const char* const sb2 = ring + ((2 * j + 1) % NR) * SLOT;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          sp_h8 ah, al;
-          sp8_split8(hv[2 * t], hv[2 * t + 1], ah, al);
+      for (int t = 0; t < 2; ++t) {
+        sp_h8 w2h[KB], w2l[KB];
 #pragma unroll
-          for (int nb = 0; nb < KB; ++nb) {
-            const char* const p = sb + nb * 4096 + frag;
-            const sp_h8 wh = *reinterpret_cast<const sp_h8*>(p + (((4 * t + 2 * h + 0) ^ swr) << 4));
-            const sp_h8 wl = *reinterpret_cast<const sp_h8*>(p + (((4 * t + 2 * h + 1) ^ swr) << 4));
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, acc2[nb], 0, 0, 0);
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, acc2[nb], 0, 0, 0);
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, acc2[nb], 0, 0, 0);
+        for (int nb = 0; nb < KB; ++nb) {
+          const char* const p = sb2 + nb * 4096 + frag;
+          w2h[nb] = *reinterpret_cast<const sp_h8*>(p + (((4 * t + 2 * h + 0) ^ swr) << 4));
+          w2l[nb] = *reinterpret_cast<const sp_h8*>(p + (((4 * t + 2 * h + 1) ^ swr) << 4));
+        }
+        sp_f4 hv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int gq = 2 * t + u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = __builtin_fmaf(acc[4 * gq + e], cw[gq][e], cb[gq][e]);
+            if constexpr (ACT == ACT_GELU) hv[u][e] = act_gelu(v) * cs[gq][e];
+            else hv[u][e] = act_mish_scaled(v, cs[gq][e]);
           }
         }
+        sp_h8 ah, al;
+        sp8_split8_mix(hv[0], hv[1], ah, al);
+#pragma unroll
+        for (int nb = 0; nb < KB; ++nb) {
+          acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[nb], ah, acc2[nb], 0, 0, 0);
+          acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[nb], al, acc2[nb], 0, 0, 0);
+          acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[nb], ah, acc2[nb], 0, 0, 0);
+        }
       }
-      rb = rb == 2 ? 0 : rb + 1;
+      // Issue order of the iteration: one MFMA, then the vector instructions that fit into its 32 cycles, 36 times over -
+      // an in-order wave that issues two MFMAs back to back idles until the matrix pipe takes the second one.
+#pragma unroll
+      for (int i = 0; i < 12 * C16 / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, 7, 0);  // VALU, TRANS
+      }
+      acc = nxt;
     }
+    const long st2 = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
     // ---- epilogue: lane (m, h) owns columns 32 nb + 8 gq + 4 h + 0..3 of its row.  Every residual quad is requested
     // before the first store (the compiler may not move a load of res above a store to Out: they could alias), so the
     // tile pays one HBM round trip, not one per quad; row scales and bias come out of the staged vectors.
@@ -278,6 +332,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpDev g) {
             *reinterpret_cast<sp_f4*>(g.Out + ro + n) = o;
           }
         }
+    }
+    if (stamp && wave == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long st3 = (long)__builtin_amdgcn_s_memtime();
+      if (lane == 0) {
+        long* d = g.stamps + (long)blockIdx.x * 8;
+        d[0] = st0, d[1] = st1, d[2] = st2, d[3] = st3, d[4] = wa, d[5] = wb;  // wb unused since the loop has one barrier
+        d[6] = (long)__builtin_amdgcn_s_getreg((15 << 11) | 4);
+        d[7] = (long)__builtin_amdgcn_s_memrealtime();
+      }
     }
   }
 }

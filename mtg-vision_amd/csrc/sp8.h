@@ -26,6 +26,28 @@ __device__ __forceinline__ void sp8_split4(const sp_f4 x, sp_h4& hi, sp_h4& lo) 
   lo = __builtin_convertvector(x - __builtin_convertvector(hi, sp_f4), sp_h4);
 }
 
+// The same split with the remainder formed by v_fma_mix_f32, which reads an fp16 operand in place: x - float(hi) is one
+// instruction per element instead of a conversion and a subtraction (the exact same value: both are exact in f32).
+// For VALU-bound producers (mlp_fused_kernel.h).
+__device__ __forceinline__ void sp8_split4_mix(const sp_f4 x, sp_h4& hi, sp_h4& lo) {
+  hi = __builtin_convertvector(x, sp_h4);
+  typedef int i2v __attribute__((ext_vector_type(2)));
+  const i2v hb = __builtin_bit_cast(i2v, hi);  // hb[0] = {hi[0], hi[1]}, hb[1] = {hi[2], hi[3]}
+  sp_f4 r;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hb[0]), "v"(x[0]));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hb[0]), "v"(x[1]));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[2]) : "v"(hb[1]), "v"(x[2]));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[3]) : "v"(hb[1]), "v"(x[3]));
+  lo = __builtin_convertvector(r, sp_h4);
+}
+__device__ __forceinline__ void sp8_split8_mix(const sp_f4 x0, const sp_f4 x1, sp_h8& hi, sp_h8& lo) {
+  sp_h4 h0, l0, h1, l1;
+  sp8_split4_mix(x0, h0, l0);
+  sp8_split4_mix(x1, h1, l1);
+  hi = sp_h8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+  lo = sp_h8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+}
+
 __device__ __forceinline__ void sp8_split8(const sp_f4 x0, const sp_f4 x1, sp_h8& hi, sp_h8& lo) {
   sp_h4 h0, l0, h1, l1;
   sp8_split4(x0, h0, l0);
