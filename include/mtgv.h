@@ -225,13 +225,16 @@ MTGV_API size_t mtgv_nms_workspace_bytes(int32_t n, int32_t na);
  * mask centroid minus hull centroid: the ray from the quad's centre along it picks the card's top edge.  Fallbacks: a
  * hull of fewer than four vertices (point, line, triangle) reports the mask's bounding box; an empty mask reports
  * boxes_dev[n] (or zeros) with ok = 0. */
+/* extents_dev: NULL, or (n, h, 2) int32 that receives every mask row's leftmost and rightmost foreground column (-1, -1 for
+ * an empty row): the outline of the mask as the host needs it for `InstanceSeg.points` (od_export.py:152-153), 2 h
+ * integers per card instead of the h x w mask. */
 MTGV_API int mtgv_mask_quads(const uint8_t* masks_dev, int32_t n, int32_t h, int32_t w, const float* boxes_dev, float* quads_dev,
-                             int32_t* ok_dev, void* stream);
+                             int32_t* ok_dev, int32_t* extents_dev, void* stream);
 /* the same from the cropped mask logits (n, mh, mw) of the detector: a pixel of the (mh*scale, mw*scale) mask is foreground
  * where the bilinear interpolation of the logits is > 0 (what mtgv_mask_binarize writes) - the full-resolution mask is
  * never materialised.  Identical quads to mtgv_mask_binarize + mtgv_mask_quads. */
 MTGV_API int mtgv_mask_quads_logits(const float* logits_dev, int32_t n, int32_t mh, int32_t mw, int32_t scale,
-                                    const float* boxes_dev, float* quads_dev, int32_t* ok_dev, void* stream);
+                                    const float* boxes_dev, float* quads_dev, int32_t* ok_dev, int32_t* extents_dev, void* stream);
 
 /* The K cards of every frame that go on to the crop stage: the K highest-confidence detections of the padded
  * mtgv_detector_forward outputs (n_det (frames), boxes (frames, max_det, 4), score-descending) or, where a frame has

@@ -37,7 +37,7 @@ constexpr int QT = 512;  // threads per block
 template <bool LOGITS>
 __global__ __launch_bounds__(QT) void mask_quads_kernel(const void* __restrict__ src, int H, int W, int scale,
                                                        const float* __restrict__ boxes, float* __restrict__ quads,
-                                                       int* __restrict__ ok) {
+                                                       int* __restrict__ ok, int* __restrict__ extents) {
   extern __shared__ __attribute__((aligned(16))) int sm_i[];
   int* xmin = sm_i;           // [H]
   int* xmax = xmin + H;       // [H]
@@ -145,7 +145,15 @@ __global__ __launch_bounds__(QT) void mask_quads_kernel(const void* __restrict__
         c += __shfl_xor(c, mask);
         sx += __shfl_xor(sx, mask);
       }
-      if (lane == 0) xmin[y] = c > 0 ? lo : -1, xmax[y] = hi, cnt[y] = c, sumx[y] = sx;
+      if (lane == 0) {
+        xmin[y] = c > 0 ? lo : -1, xmax[y] = hi, cnt[y] = c, sumx[y] = sx;
+        // the mask's outline as row extents (leftmost, rightmost foreground pixel; -1, -1 for an empty row): what the
+        // host needs of `masks.xy` (od_export.py:152-153) - 2 H integers instead of the H x W mask
+        if (extents != nullptr) {
+          extents[((size_t)n * H + y) * 2] = c > 0 ? lo : -1;
+          extents[((size_t)n * H + y) * 2 + 1] = c > 0 ? hi : -1;
+        }
+      }
     }
   }
   __syncthreads();
@@ -449,7 +457,8 @@ using namespace mtgv;
 
 namespace {
 template <bool LOGITS>
-void launch_quads(const void* src, int n, int h, int w, int scale, const float* boxes, float* quads, int* ok, hipStream_t s) {
+void launch_quads(const void* src, int n, int h, int w, int scale, const float* boxes, float* quads, int* ok, int* extents,
+                  hipStream_t s) {
   const size_t lds = (size_t)h * (4 * sizeof(int) + 3 * 2 * sizeof(P2) + 3 * 2 * sizeof(double) + 3 * 2 * sizeof(int) + 2 * sizeof(int));
   MTGV_CHECK(lds <= 150 * 1024, ERR_INVALID, "mask_quads: mask height %d exceeds the LDS capacity", h);
   static bool attr_done_dev[MTGV_MAX_DEVICES] = {};  // hipFuncSetAttribute is per device
@@ -458,7 +467,7 @@ void launch_quads(const void* src, int n, int h, int w, int scale, const float* 
     HIP_OK(hipFuncSetAttribute((const void*)mask_quads_kernel<LOGITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((mask_quads_kernel<LOGITS>), dim3(n), dim3(QT), lds, s, src, h, w, scale, boxes, quads, ok);
+  hipLaunchKernelGGL((mask_quads_kernel<LOGITS>), dim3(n), dim3(QT), lds, s, src, h, w, scale, boxes, quads, ok, extents);
   HIP_OK(hipGetLastError());
 }
 }  // namespace
@@ -466,22 +475,23 @@ void launch_quads(const void* src, int n, int h, int w, int scale, const float* 
 extern "C" {
 
 MTGV_API int mtgv_mask_quads(const uint8_t* masks_dev, int32_t n, int32_t h, int32_t w, const float* boxes_dev, float* quads_dev,
-                             int32_t* ok_dev, void* stream) {
+                             int32_t* ok_dev, int32_t* extents_dev, void* stream) {
   return guarded([&] {
     MTGV_CHECK(n >= 0 && h > 0 && w > 0, ERR_INVALID, "mask_quads: n=%d h=%d w=%d", n, h, w);
     if (n == 0) return;
     MTGV_CHECK(masks_dev != nullptr && quads_dev != nullptr && ok_dev != nullptr, ERR_INVALID, "mask_quads: null argument");
-    launch_quads<false>(masks_dev, n, h, w, 1, boxes_dev, quads_dev, (int*)ok_dev, (hipStream_t)stream);
+    launch_quads<false>(masks_dev, n, h, w, 1, boxes_dev, quads_dev, (int*)ok_dev, (int*)extents_dev, (hipStream_t)stream);
   });
 }
 
 MTGV_API int mtgv_mask_quads_logits(const float* logits_dev, int32_t n, int32_t mh, int32_t mw, int32_t scale, const float* boxes_dev,
-                                    float* quads_dev, int32_t* ok_dev, void* stream) {
+                                    float* quads_dev, int32_t* ok_dev, int32_t* extents_dev, void* stream) {
   return guarded([&] {
     MTGV_CHECK(n >= 0 && mh > 0 && mw > 0 && scale > 0, ERR_INVALID, "mask_quads_logits: n=%d mh=%d mw=%d scale=%d", n, mh, mw, scale);
     if (n == 0) return;
     MTGV_CHECK(logits_dev != nullptr && quads_dev != nullptr && ok_dev != nullptr, ERR_INVALID, "mask_quads_logits: null argument");
-    launch_quads<true>(logits_dev, n, mh * scale, mw * scale, scale, boxes_dev, quads_dev, (int*)ok_dev, (hipStream_t)stream);
+    launch_quads<true>(logits_dev, n, mh * scale, mw * scale, scale, boxes_dev, quads_dev, (int*)ok_dev, (int*)extents_dev,
+                       (hipStream_t)stream);
   });
 }
 }

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import spec
-from .crop import mask_quads, warp_quads
+from .crop import mask_quads_from_logits, warp_quads
 from .detector import Detector, binarize_masks, letterbox
 from .encoder import Encoder
 from .matcher import Matcher
@@ -297,10 +297,17 @@ class CardSegmenter:
     models are not loadable without the package (and are never unpickled here)."""
 
     def __init__(self, model_path: str | Path = None, *, state_dict=None, detector: Optional[Detector] = None, max_batch: int = 1,
-                 contours: bool = True):
-        """contours=True (reference behaviour): `InstanceSeg.points` is the traced outline of the mask and the quad is
-        fitted lazily on the host.  contours=False: the oriented quad comes from the GPU (`mask_quads`, quads.hip) and
-        doubles as `points`; nothing but four corners per card leaves the device - the fast path for tracking loops."""
+                 contours="outline"):
+        """contours: what `InstanceSeg.points` holds (the reference: ultralytics `masks.xy`, od_export.py:152-153).
+        "outline" (default; True is accepted for it): the mask's outline as the GPU's row extents - left edge top to
+        bottom, right edge bottom to top, at most 2 x 640 points - with the oriented quad fitted on the GPU
+        (quads.hip); one device-to-host copy of those integers per call, no mask leaves the device.
+        "trace": every 640 x 640 mask is copied to the host and its blobs are traced there like
+        cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) (`_mask_segments`; scipy), the quad fitted lazily on the host.
+        False: only the four GPU-fitted corners per card (they double as `points`) - for tracking loops."""
+        if contours is True:
+            contours = "outline"
+        assert contours in ("outline", "trace", False), contours
         self.contours = contours
         if detector is not None:
             self.yolo = detector
@@ -316,31 +323,46 @@ class CardSegmenter:
         img, ratio, (left, top) = letterbox(rgb_im, self.yolo.cfg.imgsz)
         det = self.yolo.detect(rgb_im)
         detections = []
-        if not self.contours and det.mask_logits is not None and det.conf.numel() > 0:
-            quads, ok = mask_quads(binarize_masks(det.mask_logits), det.boxes_xyxy)
-            quads = (quads.cpu().numpy().astype(np.float64) - np.asarray([left, top], np.float64)) / float(ratio)
-            quads[..., 0] = np.clip(quads[..., 0], 0, rgb_im.shape[1])
-            quads[..., 1] = np.clip(quads[..., 1], 0, rgb_im.shape[0])
-            for q, good, conf in zip(quads, ok.cpu().numpy(), det.conf.cpu().numpy()):
-                if not good:
-                    continue
-                seg = InstanceSeg(points=q.astype(np.float32), label=0, conf=np.asarray(conf).tolist())
-                top_mid, centre = (q[0] + q[1]) / 2, q.mean(0)
-                v = top_mid - centre
-                seg._xyxyxyxy, seg._points_closed = q.astype(int), q.astype(int)
-                seg._dir_vec = v / (np.linalg.norm(v) or 1.0)
-                detections.append(seg)
+        if det.mask_logits is None or det.conf.numel() == 0:
             return detections
-        if det.mask_logits is not None and det.conf.numel() > 0:
+        fh, fw = rgb_im.shape[0], rgb_im.shape[1]
+
+        def to_frame(p):  # scale_coords + clip_coords back to the caller's frame
+            p = (np.asarray(p, np.float64) - np.asarray([left, top], np.float64)) / float(ratio)
+            p[..., 0] = np.clip(p[..., 0], 0, fw)
+            p[..., 1] = np.clip(p[..., 1], 0, fh)
+            return p
+
+        if self.contours == "trace":
             masks = binarize_masks(det.mask_logits).cpu().numpy()
             for m, conf in zip(masks, det.conf.cpu().numpy()):
                 pts = _mask_segments(m)  # masks.xy: all blobs' outlines, run end points
                 if len(pts) == 0:
                     continue
-                pts = (pts - np.asarray([left, top], np.float32)) / np.float32(ratio)  # scale_coords back to the frame
-                pts[:, 0] = np.clip(pts[:, 0], 0, rgb_im.shape[1])  # clip_coords
-                pts[:, 1] = np.clip(pts[:, 1], 0, rgb_im.shape[0])
-                detections.append(InstanceSeg(points=np.asarray(pts), label=0, conf=np.asarray(conf).tolist()))
+                detections.append(InstanceSeg(points=to_frame(pts).astype(np.float32), label=0, conf=np.asarray(conf).tolist()))
+            return detections
+        # quads (and row extents) straight from the mask logits on the GPU; one small copy to the host
+        want_ext = self.contours == "outline"
+        res = mask_quads_from_logits(det.mask_logits, det.boxes_xyxy, extents=want_ext)
+        quads, ok = to_frame(res[0].cpu().numpy()), res[1].cpu().numpy()
+        ext = res[2].cpu().numpy() if want_ext else None
+        for i, (q, good, conf) in enumerate(zip(quads, ok, det.conf.cpu().numpy())):
+            if not good:
+                continue
+            if want_ext:
+                rows = np.nonzero(ext[i, :, 0] >= 0)[0]
+                left_edge = np.stack([ext[i, rows, 0], rows], 1)            # top to bottom
+                right_edge = np.stack([ext[i, rows[::-1], 1], rows[::-1]], 1)  # bottom to top
+                pts = to_frame(np.concatenate([left_edge, right_edge])).astype(np.float32)
+            else:
+                pts = q.astype(np.float32)
+            seg = InstanceSeg(points=pts, label=0, conf=np.asarray(conf).tolist())
+            top_mid, centre = (q[0] + q[1]) / 2, q.mean(0)
+            v = top_mid - centre
+            seg._xyxyxyxy = q.astype(int)
+            seg._points_closed = pts.astype(int) if want_ext else q.astype(int)
+            seg._dir_vec = v / (np.linalg.norm(v) or 1.0)
+            detections.append(seg)
         return detections
 
 

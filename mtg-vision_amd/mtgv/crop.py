@@ -60,8 +60,9 @@ def boxes_to_quads(boxes_xyxy: torch.Tensor) -> torch.Tensor:
     return torch.stack([torch.stack([x1, y1], -1), torch.stack([x2, y1], -1), torch.stack([x2, y2], -1), torch.stack([x1, y2], -1)], -2)
 
 
-def mask_quads(masks_u8: torch.Tensor, boxes_xyxy: torch.Tensor = None):
-    """masks (n, H, W) uint8 on the GPU (non-zero = card) -> (quads (n, 4, 2) float32, ok (n,) int32).
+def mask_quads(masks_u8: torch.Tensor, boxes_xyxy: torch.Tensor = None, extents: bool = False):
+    """masks (n, H, W) uint8 on the GPU (non-zero = card) -> (quads (n, 4, 2) float32, ok (n,) int32)
+    [, extents (n, H, 2) int32: leftmost / rightmost foreground column of every row, -1 where the row is empty].
 
     The quad is the 4-vertex polygon cv2.approxPolyN would fit to the mask's hull, rolled so that corner 0 is the
     card's top-left, corners truncated to integers - the GPU form of `InstanceSeg._orient`
@@ -72,31 +73,33 @@ def mask_quads(masks_u8: torch.Tensor, boxes_xyxy: torch.Tensor = None):
     n, h, w = masks_u8.shape
     quads = torch.zeros((n, 4, 2), dtype=torch.float32, device=masks_u8.device)
     ok = torch.zeros((n,), dtype=torch.int32, device=masks_u8.device)
+    ext = torch.empty((n, h, 2), dtype=torch.int32, device=masks_u8.device) if extents else None
     if n == 0:
-        return quads, ok
+        return (quads, ok, ext) if extents else (quads, ok)
     if boxes_xyxy is not None:
         boxes_xyxy = boxes_xyxy.to(masks_u8.device, torch.float32).contiguous()
         assert tuple(boxes_xyxy.shape) == (n, 4), f"{tuple(boxes_xyxy.shape)}"
     with torch.cuda.device(masks_u8.device):
         native.check(native.lib().mtgv_mask_quads(native.ptr(masks_u8.contiguous()), n, h, w, native.ptr(boxes_xyxy), native.ptr(quads),
-                                                  native.ptr(ok), native.stream()))
-    return quads, ok
+                                                  native.ptr(ok), native.ptr(ext), native.stream()))
+    return (quads, ok, ext) if extents else (quads, ok)
 
 
-def mask_quads_from_logits(mask_logits: torch.Tensor, boxes_xyxy: torch.Tensor = None, scale: int = 4):
-    """(n, mh, mw) cropped mask logits -> (quads, ok) of the (mh*scale, mw*scale) masks `binarize_masks` would produce,
-    without materialising them (one kernel: interpolate, threshold, row extents, hull, approxPolyN, orientation)."""
+def mask_quads_from_logits(mask_logits: torch.Tensor, boxes_xyxy: torch.Tensor = None, scale: int = 4, extents: bool = False):
+    """(n, mh, mw) cropped mask logits -> (quads, ok [, extents]) of the (mh*scale, mw*scale) masks `binarize_masks` would
+    produce, without materialising them (one kernel: interpolate, threshold, row extents, hull, approxPolyN, orientation)."""
     native.require_gpu()
     assert mask_logits.is_cuda and mask_logits.dtype == torch.float32 and mask_logits.ndim == 3
     n, mh, mw = mask_logits.shape
     quads = torch.empty((n, 4, 2), dtype=torch.float32, device=mask_logits.device)  # the kernel writes every row
     ok = torch.empty((n,), dtype=torch.int32, device=mask_logits.device)
+    ext = torch.empty((n, mh * scale, 2), dtype=torch.int32, device=mask_logits.device) if extents else None
     if n == 0:
-        return quads, ok
+        return (quads, ok, ext) if extents else (quads, ok)
     if boxes_xyxy is not None:
         boxes_xyxy = boxes_xyxy.to(mask_logits.device, torch.float32).contiguous()
         assert tuple(boxes_xyxy.shape) == (n, 4), f"{tuple(boxes_xyxy.shape)}"
     with torch.cuda.device(mask_logits.device):
         native.check(native.lib().mtgv_mask_quads_logits(native.ptr(mask_logits.contiguous()), n, mh, mw, scale, native.ptr(boxes_xyxy),
-                                                         native.ptr(quads), native.ptr(ok), native.stream()))
-    return quads, ok
+                                                         native.ptr(quads), native.ptr(ok), native.ptr(ext), native.stream()))
+    return (quads, ok, ext) if extents else (quads, ok)

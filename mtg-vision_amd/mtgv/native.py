@@ -95,8 +95,8 @@ SIGNATURES = {
     "mtgv_select_cards": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mtgv_warp_workspace_bytes": (C.c_size_t, [c_i32]),
     "mtgv_warp_quads": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, C.c_double, c_vp, c_vp, C.c_size_t, c_vp]),
-    "mtgv_mask_quads": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
-    "mtgv_mask_quads_logits": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "mtgv_mask_quads": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mtgv_mask_quads_logits": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mtgv_make_cropped": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mtgv_op_linear": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "mtgv_op_linear_ex_part_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32]),

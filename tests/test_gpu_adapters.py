@@ -166,7 +166,7 @@ def test_card_segmenter_gpu_quads_fast_path():
     cfg = spec.DetectorConfig()
     det = Detector(cfg, spec.random_detector_state(cfg, 3), max_batch=1)
     frame = np.random.default_rng(8).integers(0, 256, (480, 640, 3), dtype=np.uint8)
-    slow = CardSegmenter(detector=det)(frame)
+    slow = CardSegmenter(detector=det, contours="trace")(frame)
     fast = CardSegmenter(detector=det, contours=False)(frame)
     assert len(fast) > 0 and len(fast) <= len(slow) + 0
     assert all(s.points.shape == (4, 2) and s.xyxyxyxy.shape == (4, 2) and s.xyxyxyxy.dtype.kind == "i" for s in fast)
@@ -183,3 +183,51 @@ def test_card_segmenter_gpu_quads_fast_path():
         b = np.sort(np.asarray(h.xyxyxyxy, float), axis=0)
         close += int(np.abs(a - b).max() <= 2.0)
     print(f"{len(fast)} fast / {len(slow)} host segments, {close} with the same corners")
+
+
+def _card_frame_mask(quad, size=640):
+    """binary mask of a convex quadrilateral with a bite out of its bottom edge (the reference's U-shaped card masks)"""
+    yy, xx = np.mgrid[0:size, 0:size]
+    m = np.ones((size, size), bool)
+    q = np.asarray(quad, np.float64)
+    for i in range(4):
+        a, b = q[i], q[(i + 1) % 4]
+        m &= (b[0] - a[0]) * (yy - a[1]) - (b[1] - a[1]) * (xx - a[0]) >= 0
+    c = (q[2] + q[3]) / 2
+    m &= ~(((xx - c[0]) ** 2 + (yy - c[1]) ** 2) < 30**2)
+    return m
+
+
+def test_card_segmenter_default_outline_from_the_device(monkeypatch):
+    """default path (contours="outline"): points = the mask's row-extent outline computed on the GPU, quad fitted on the
+    GPU; against the host path that copies the masks and traces them (contours="trace") on card-shaped masks: same cards,
+    corners within 1.5 px, and the outline is a polygon of at most 2 x 640 points that covers the mask."""
+    import mtgv.adapters as A
+    from mtgv import spec
+    from mtgv.detector import Detections, Detector
+
+    cfg = spec.DetectorConfig()
+    det = Detector(cfg, spec.random_detector_state(cfg, 3), max_batch=1)
+    frame = np.zeros((640, 640, 3), np.uint8)
+    quads = [[(120, 80), (330, 110), (300, 420), (90, 380)], [(400, 300), (560, 290), (590, 520), (420, 540)]]
+    masks = np.stack([_card_frame_mask(q) for q in quads])
+    # mask logits on the 160 x 160 grid whose x4 bilinear interpolation crosses zero on the shapes' boundaries
+    big = torch.from_numpy(np.where(masks, 4.0, -4.0).astype(np.float32))[:, None]
+    logits = torch.nn.functional.avg_pool2d(big, 4)[:, 0].cuda().contiguous()
+    boxes = torch.tensor([[90.0, 80.0, 330.0, 420.0], [400.0, 290.0, 590.0, 540.0]], device="cuda")
+    fake = Detections(boxes, torch.tensor([0.9, 0.8], device="cuda"), torch.zeros(2, dtype=torch.int64, device="cuda"),
+                      torch.zeros(2, dtype=torch.int64, device="cuda"), logits)
+    monkeypatch.setattr(det, "detect", lambda *a, **k: fake)
+    seg_dev = A.CardSegmenter(detector=det)(frame)
+    seg_host = A.CardSegmenter(detector=det, contours="trace")(frame)
+    assert len(seg_dev) == len(seg_host) == 2
+    for d, h, q in zip(seg_dev, seg_host, quads):
+        assert d.points.ndim == 2 and d.points.shape[1] == 2 and 8 < d.points.shape[0] <= 2 * 640
+        a, b = np.asarray(d.xyxyxyxy, float), np.asarray(h.xyxyxyxy, float)
+        assert np.abs(a - b).max() <= 1.5, (a, b)                      # same corners, same order (corner 0 = top-left of the card)
+        assert np.abs(a - np.asarray(q, float)).max() <= 6.0, (a, q)    # and they are the card's corners (mask grid: 4 px)
+        # the device outline and the traced outline describe the same region: equal hulls up to a pixel
+        area = lambda p: 0.5 * abs(np.sum(p[:, 0] * np.roll(p[:, 1], -1) - np.roll(p[:, 0], -1) * p[:, 1]))  # noqa: E731
+        hd, hh = A._convex_hull(np.asarray(d.points, np.float64)), A._convex_hull(np.asarray(h.points, np.float64))
+        assert abs(area(hd) - area(hh)) <= 0.01 * area(hh)
+        assert d.extract_dewarped(frame).shape == (192, 128, 3)

@@ -120,9 +120,9 @@ def test_degenerate_masks_and_errors():
     assert (q2[0] == 0).all() and ok2[0] == 0
     assert _gpu(np.zeros((0, h, w), np.uint8))[0].shape == (0, 4, 2)
     with pytest.raises(AssertionError):
-        native.check(native.lib().mtgv_mask_quads(None, 1, 8, 8, None, None, None, None))
+        native.check(native.lib().mtgv_mask_quads(None, 1, 8, 8, None, None, None, None, None))
     with pytest.raises(AssertionError):
-        native.check(native.lib().mtgv_mask_quads(None, 1, 4096, 8, None, None, None, None))  # taller than the LDS tables
+        native.check(native.lib().mtgv_mask_quads(None, 1, 4096, 8, None, None, None, None, None))  # taller than the LDS tables
 
 
 def test_pipeline_mask_quads_match_oracle():
