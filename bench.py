@@ -37,6 +37,8 @@ def group_launches(recs, nprof, precision):
     """Per-group roofline view of the GEMM launches of one step (records of mtgv_profile_gemm_dump over nprof passes).
     Groups: pwconv1 (1x1 + activation + GRN partials), pwconv2 (GRN-scaled 1x1 + residual), bank (scores + top-k),
     det3x3 / det1x1 (detector convolutions), enc_other (stem, downsample, head)."""
+    peak = PEAK_MFMA_TFLOPS[precision]
+    mult = MFMA_FLOPS_PER_FLOP[precision]
     per = max(1, len(recs) // nprof)
     # launch order inside one pass: detector, then the encoder (whose first launch is the 4x4 stem), then the bank
     enc_start = min((i for i, r in enumerate(recs[:per]) if int(r["KH"]) == 4 or int(r["grn"])), default=per)
@@ -53,14 +55,18 @@ def group_launches(recs, nprof, precision):
             g = "det3x3" if int(r["KH"]) == 3 else "det1x1"
         else:
             g = "enc_other"
-        d = out.setdefault(g, {"launches": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0, "fill": 0.0})
+        d = out.setdefault(g, {"launches": 0, "ms": 0.0, "flop": 0.0, "issued": 0.0, "bytes": 0.0, "fill": 0.0})
         d["launches"] += 1
         d["ms"] += float(r["ms"])
-        d["flop"] += 2.0 * int(r["M"]) * int(r["N"]) * int(r["K"]) * int(r["batch"])
+        fl = 2.0 * int(r["M"]) * int(r["N"]) * int(r["K"]) * int(r["batch"])
+        d["flop"] += fl
+        # MFMA FLOPs issued per algorithmic FLOP: 3 for the split products, 1 for f32 operands and for the fp16 first
+        # pass of the two-pass bank match (sp = 3), 6 for the fused MLP's output pass (sp = 2 with a GRN-scaled A:
+        # GEMM1 is computed again, so 2 x 3 products for the pwconv2 FLOPs it is credited with)
+        sp = int(r.get("sp", 0) or 0)
+        d["issued"] += fl * (1 if sp == 3 else (2 * mult if sp == 2 and int(r["apro"]) else mult))
         d["bytes"] += float(r.get("bytes", 0) or 0)
         d["fill"] += float(r.get("fill", 0) or 0)
-    peak = PEAK_MFMA_TFLOPS[precision]
-    mult = MFMA_FLOPS_PER_FLOP[precision]
     res = {}
     for g, d in out.items():
         sec = d["ms"] * 1e-3
@@ -69,7 +75,8 @@ def group_launches(recs, nprof, precision):
             "launches_per_step": d["launches"] // nprof,
             "ms_per_step": round(d["ms"] / nprof, 3),
             "algorithmic_tflops": round(tf, 1),
-            "issued_mfma_frac": round(tf * mult / peak, 4),
+            "issued_mfma_frac": round(d["issued"] / sec / 1e12 / peak, 4) if sec > 0 else 0.0,
+            "issued_gflop_per_step": round(d["issued"] / nprof / 1e9, 2),
             "compulsory_gbs": round(d["bytes"] / sec / 1e9, 1) if sec > 0 else 0.0,
             "hbm_frac": round(d["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4) if sec > 0 else 0.0,
             # what the tiles of the group pull through L2 into LDS (every tile its A and B panels), per second
@@ -354,6 +361,8 @@ def main():
             gbs = gemm_bytes / sec / 1e9 if sec > 0 else 0.0
             peak_tf = PEAK_MFMA_TFLOPS[precision]
             issued = tfl * MFMA_FLOPS_PER_FLOP[precision]
+            if groups:  # exact per launch kind (the fp16 first pass of the bank match issues 1x, the fused MLP's output pass 6x)
+                issued = sum(gv["issued_gflop_per_step"] for gv in groups.values()) / 1e3 / sec if sec > 0 else 0.0
             traffic, traffic_src = None, None
             tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")
             if os.path.exists(tfile):

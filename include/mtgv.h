@@ -156,6 +156,12 @@ MTGV_API int mtgv_bank_get_rows(const mtgv_bank* h, int64_t row, int64_t n, floa
  * fewer than k rows); -INFINITY keeps everything, NaN is rejected. */
 MTGV_API int mtgv_bank_topk(mtgv_bank* h, const float* q_dev, int32_t b, int32_t k, int64_t id_base, float score_threshold,
                             int64_t* ids_dev, float* scores_dev, void* stream);
+/* Batches of >= 128 queries (dim % 64 == 0, k <= 4, F16X3 mode) are matched in two passes: approximate fp16 scores over a
+ * hi-only copy of the bank, then an exact re-rank of the best candidates with a bound that proves no other row can enter
+ * the top k; a query whose bound fails is scanned exactly, so the answer is always the exact top k.  count: how many
+ * queries took that scan so far (banks with many near-duplicate rows); synchronises the device.  MTGV_MATCH_PREPASS=0
+ * keeps to the one-pass exact kernel. */
+MTGV_API int mtgv_bank_prepass_fallbacks(const mtgv_bank* h, int64_t* count);
 /* merge ncand (score,id) candidates per query into the top k (multi-GPU shard merge); same threshold rule */
 MTGV_API int mtgv_topk_merge(float* cand_scores_dev, const int64_t* cand_ids_dev, int32_t b, int32_t ncand, int32_t k,
                              float score_threshold, int64_t* ids_dev, float* scores_dev, void* stream);

@@ -224,6 +224,12 @@ MTGV_API int mtgv_bank_topk(mtgv_bank* h, const float* q_dev, int32_t b, int32_t
     h->impl.topk(q_dev, b, k, id_base, score_threshold, ids_dev, scores_dev, (hipStream_t)stream);
   });
 }
+MTGV_API int mtgv_bank_prepass_fallbacks(const mtgv_bank* h, int64_t* count) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr && count != nullptr, ERR_INVALID, "null argument");
+    *count = h->impl.prepass_fallbacks();
+  });
+}
 MTGV_API int mtgv_topk_merge(float* cand_scores_dev, const int64_t* cand_ids_dev, int32_t b, int32_t ncand, int32_t k,
                              float score_threshold, int64_t* ids_dev, float* scores_dev, void* stream) {
   return guarded([&] {

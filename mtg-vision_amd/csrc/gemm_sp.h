@@ -23,6 +23,7 @@ struct SpPlan {
 
 // f16x3 operand mode with the LDS-DMA kernel enabled (MTGV_GEMM_SP != 0): executors then keep activations in SP8
 bool gemm_sp_active();
+bool topk_sp_on();  // MTGV_SP_TOPK != 0: bank matches of >= 128 queries on the LDS-DMA kernel
 // Can (and should) this launch run on the SP kernel?  a.a_fmt says how A is stored.
 SpPlan gemm_sp_plan(const GemmArgs& a);
 // true when a dense [M][K] x [N][K]^T launch with these sizes would take SP8 activations (producer kernels ask before
@@ -32,6 +33,15 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s);
 bool gemm_sp_topk_layout(const GemmArgs& a, int* slots, int* cols);  // candidate groups of a top-k launch the SP kernel takes
 double gemm_sp_fill_bytes(const GemmArgs& a, const SpPlan& pl);  // LDS fill bytes of the launch (profiling aid)
 void gemm_sp_stamps_dump(const char* path);  // tuning aid, see gemm_sp.hip
+
+// Approximate scores for the bank match's first pass: q_hi [b][K] and bank_hi [N][K] are fp16 rows (the hi halves of the
+// exact operands, the bank's scaled per row by 1 / wscale), one fp16 MFMA per product; per (query, 96-column wave
+// range) the kp best (score, column) pairs go to cand_s / cand_i like the exact top-k launch's.  128 x 192 tiles;
+// b >= 128, N >= 192, K % 64 == 0.  *slots = candidate groups per query.
+void gemm_sp_topk_hi16_launch(const void* q_hi, const void* bank_hi, const float* wscale, int b, int N, int K, int kp, float* cand_s,
+                              int* cand_i, int* slots, hipStream_t s);
+int gemm_sp_topk_hi16_slots(int N);
+int gemm_sp_topk_hi16_range_cols();  // columns per candidate group: group w covers columns [w * cols, (w + 1) * cols)
 
 // >= 256 zero bytes on the current device (K tails and padding taps of the DMA paths read them)
 const char* sp_zero_page();

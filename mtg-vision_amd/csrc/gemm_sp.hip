@@ -328,6 +328,30 @@ void gemm_sp_stamps_dump(const char* path) {
   g_stamps.clear();
 }
 
+int gemm_sp_topk_hi16_range_cols() { return 32 * kCfg[1].tn; }
+int gemm_sp_topk_hi16_slots(int N) { return ceil_div(N, kCfg[1].bn()) * kCfg[1].wn; }
+
+void gemm_sp_topk_hi16_launch(const void* q_hi, const void* bank_hi, const float* wscale, int b, int N, int K, int kp, float* cand_s,
+                              int* cand_i, int* slots, hipStream_t s) {
+  const SpCfg& k1 = kCfg[1];
+  MTGV_CHECK(b >= 128 && N >= k1.bn() && K % 64 == 0 && kp >= 1 && kp <= 32 * k1.tn, ERR_INVALID, "topk_hi16: b=%d N=%d K=%d kp=%d", b, N, K, kp);
+  MTGV_CHECK(((uintptr_t)q_hi & 15) == 0 && ((uintptr_t)bank_hi & 15) == 0, ERR_INVALID, "topk_hi16: operands must be 16-byte aligned");
+  SpDev g;
+  g.A = reinterpret_cast<const char*>(q_hi);
+  g.a_rowb = (long)K * 2;
+  g.W = reinterpret_cast<const char*>(bank_hi);
+  g.wscale = wscale;
+  g.M = b, g.N = N, g.K = K;
+  g.zero = sp_zero_page();
+  g.off32 = ((double)N * K * 2.0 < 4294967296.0 - 65536.0) ? 1 : 0;
+  g.tiles_m = ceil_div(b, k1.bm()), g.tiles_n = ceil_div(N, k1.bn());
+  g.cand_s = cand_s, g.cand_i = cand_i, g.topk = kp;
+  g.d_hw = make_fastdiv(1), g.d_ohw = make_fastdiv(1), g.d_ow = make_fastdiv(1), g.d_cin = make_fastdiv(1), g.d_kw = make_fastdiv(1);
+  if (slots) *slots = g.tiles_n * k1.wn;
+  gemm_sp_launch_cfg1(g, 6, s);
+  HIP_OK(hipGetLastError());
+}
+
 void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   MTGV_CHECK(pl.cfg >= 0 && pl.cfg < kNumCfg, ERR_INVALID, "gemm_sp: no plan");
   SpDev g;

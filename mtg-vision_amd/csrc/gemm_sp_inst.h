@@ -1,6 +1,8 @@
 // One tile configuration of the LDS-DMA split GEMM per translation unit (they compile in parallel): a file defines
 // SP_CFG_ID, SP_WM, SP_WN, SP_TM, SP_TN and includes this header.
 #pragma once
+#include <stdlib.h>
+
 #include "gemm_sp_kernel.h"
 
 namespace mtgv {
@@ -11,10 +13,10 @@ constexpr int SP_KS = 2;
 #define SP_NST 2
 #endif
 
-template <int AMODE, int ACT, int EPI>
-void sp_launch_one(const SpDev& g, hipStream_t s) {
+template <int AMODE, int ACT, int EPI, int NST = SP_NST>
+void sp_launch_nst(const SpDev& g, hipStream_t s) {
   constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN;
-  constexpr size_t ring = (size_t)SP_NST * ((AMODE == 5 ? BN : BM + BN) * 64 * SP_KS + (AMODE == 3 ? 1024 : 0));
+  constexpr size_t ring = (size_t)NST * ((AMODE == 5 ? BN : BM + BN) * 64 * SP_KS + (AMODE == 3 ? 1024 : 0));
   size_t lds = ring;
   if (AMODE == 5) {  // window of BM + 2 W + 2 pixels x 128 B in front of the weight ring; the epilogue stages 32 rows per wave
     const size_t win = (size_t)((BM + 2 * g.Wd + 2 + 7) & ~7) * 128;
@@ -23,12 +25,29 @@ void sp_launch_one(const SpDev& g, hipStream_t s) {
   }
   static bool attr_done_dev[MTGV_MAX_DEVICES] = {};  // hipFuncSetAttribute is per device
   bool& attr_done = attr_done_dev[current_device()];
-  auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, SP_NST, AMODE, ACT, EPI>;
+  auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, NST, AMODE, ACT, EPI>;
   if (!attr_done) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AMODE == 5 ? 160 * 1024 : (int)lds));
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * SP_WM * SP_WN), lds, s, g);
+}
+
+template <int AMODE, int ACT, int EPI>
+void sp_launch_one(const SpDev& g, hipStream_t s) {
+  if constexpr (AMODE == 5 && SP_NST == 2) {
+    // window conv: a four-deep weight ring (three taps ahead) for launches of at most one round of tiles - there a tile's
+    // latency is the launch's duration (12800-row layers -15..-25 %); with several rounds the blocks per CU matter more
+    // (the deeper ring costs one: 204800 x 32 layers +12 %) and the two-deep ring stays
+    constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN;
+    const size_t win = (size_t)((BM + 2 * g.Wd + 2 + 7) & ~7) * 128;
+    static const bool deep_on = [] { const char* e = getenv("MTGV_SP_WINRING"); return e == nullptr || atoi(e) != 0; }();
+    if (deep_on && (long)g.tiles_m * g.tiles_n <= 512 && win + (size_t)4 * BN * 128 <= 80 * 1024) {
+      sp_launch_nst<AMODE, ACT, EPI, 4>(g, s);
+      return;
+    }
+  }
+  sp_launch_nst<AMODE, ACT, EPI, SP_NST>(g, s);
 }
 
 // the compile-time epilogue shape of a launch (gemm_sp_kernel.h, EPI), or -1 when only the generic one fits
@@ -59,8 +78,9 @@ void sp_pick(const SpDev& g, int epi, hipStream_t s) {
 void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_t s) {
   if (g.topk > 0) {  // match path: f32 queries by DMA, fused top-k epilogue; only the 128 x 192 configuration carries it
 #if SP_CFG_ID == 1
-    MTGV_CHECK(amode == 4 && g.act == ACT_NONE, ERR_INVALID, "gemm_sp: top-k needs aligned f32 queries");
-    sp_launch_one<4, ACT_NONE, 16>(g, s);
+    MTGV_CHECK((amode == 4 || amode == 6) && g.act == ACT_NONE, ERR_INVALID, "gemm_sp: top-k needs aligned f32 queries");
+    if (amode == 6) sp_launch_one<6, ACT_NONE, 16>(g, s);  // fp16 rows on both sides: the approximate first pass
+    else sp_launch_one<4, ACT_NONE, 16>(g, s);
     return;
 #else
     MTGV_CHECK(false, ERR_INVALID, "gemm_sp: no top-k instance in this configuration");

@@ -17,6 +17,8 @@
 //   A, AMODE 3 / 4       f32 rows by LDS-DMA; the wave that feeds a fragment to the MFMAs multiplies it by the per-image
 //                        multipliers (AMODE 3: GRN apply, convnextv2.py:171-174; one extra 1 KB DMA piece per stage holds
 //                        [8 images][32 k]) and splits it into hi / lo on the spot.
+//   A, AMODE 6 (HI16)    A and B are plain fp16 rows (the hi halves only, 2 bytes per element): a stage is 64 k, one MFMA
+//                        per k16 step.  The approximate first pass of the bank match (match.hip); K % 64 == 0.
 //   A, AMODE 1 (REG)     f32 rows: global -> VGPR (issued before the stage's MFMAs) -> optional per-image multiplier
 //                        -> split -> ds_write_b128 (after the MFMAs).  Fallback of 3 / 4: unaligned rows, range-guarded
 //                        inputs (a_mul != 1), tiles spanning more than 8 images.
@@ -93,8 +95,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   constexpr bool AWIN = AMODE == 5;  // 3x3 / stride 1 / pad 1 conv: the tile's input window is staged once per 32 channels
   constexpr bool ADMA = AMODE != 1 && !AWIN;
   constexpr bool AF32 = AMODE == 3 || AMODE == 4;  // f32 rows by DMA, split into hi / lo when a fragment is read
+  constexpr bool HI16 = AMODE == 6;                // fp16 rows on both sides: 2 bytes per element, 64 k per 128-byte stage row
+  constexpr int EB = HI16 ? 2 : 4;                 // bytes per operand element in memory
+  static_assert(!HI16 || (KS == 2 && EPI == 16), "fp16 rows: 128-byte stage rows, top-k epilogue");
   constexpr int SA = AWIN ? 0 : BM * RB, SB = BN * RB, SSC = AMODE == 3 ? 1024 : 0, STG = SA + SB + SSC;
-  static_assert(!AWIN || (KS == 2 && NST == 2), "window conv: 32-channel stages, two-deep weight ring");
+  static_assert(!AWIN || KS == 2, "window conv: 32-channel stages");
   static_assert(AMODE != 3 || KS == 2, "the scale image is one DMA piece: 8 images x 32 k");
   constexpr int PA = ADMA ? BM / RPP : 0, PB = BN / RPP, NP = PA + PB;
   constexpr int PPW = (NP + NW - 1) / NW;
@@ -118,10 +123,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   }
   const int tile_n = L % g.tiles_n, tile_m = L / g.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const long wrowb = (long)g.K * 4;
+  const long wrowb = (long)g.K * EB;
   const int kchunks = g.K >> 3;                 // valid 8-float chunks per row
-  const int nk = (g.K + 16 * KS - 1) / (16 * KS);
-  const bool ktail = (g.K % (16 * KS)) != 0;
+  constexpr int KPS = 16 * KS * (4 / EB);       // k per stage
+  const int nk = (g.K + KPS - 1) / KPS;
+  const bool ktail = (g.K % KPS) != 0;          // (never with fp16 rows: the host requires K % 64 == 0)
 
   // ---- DMA pieces: piece p = wave + NW*u of the stage image (A pieces first, then B) ----
   const char* src[PPW];   // dense A / B: address of the lane's slot in stage 0.  CONV A: pixel (img, 0, 0) of the row
@@ -311,7 +317,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   // The first stages are requested now, before the rest of the set-up (accumulators, fragment offsets, epilogue
   // constants): their latency runs under it.
   if constexpr (AWIN) {
-    issue(0, 0);  // weights of (slice 0, tap 0): K index of (tap, slice) is tap * Cin + 32 * slice
+    // weights of the first NST - 1 (slice, tap) steps: step tau = 9 cc + tap reads K stage tap * (Cin / 32) + cc
+    const int ncc0 = g.Cin >> 5;
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+      if (s0 < 9 * ncc0) issue((s0 % 9) * ncc0 + s0 / 9, s0);
     issue_window(0);
   } else {
 #pragma unroll
@@ -411,21 +421,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
 
   if constexpr (AWIN) {
     // per 32-channel slice: stage the window once, then 9 taps x 2 k-steps out of it while the taps' weight stages
-    // ring through two buffers.  Accumulation order: channel slice outer, tap inner.
+    // ring through NST buffers (NST - 1 taps ahead: a tap's 6 TN MFMAs are far shorter than a DMA round trip, so the
+    // two-deep ring stalled on every tap).  Accumulation order: channel slice outer, tap inner.
     const int ncc = g.Cin >> 5;
+    const int ntau = 9 * ncc;
     const char* const win = smem;
-    int buf = 0;
+    int buf = 0, nbuf = NST - 1;
+    int tau = 0;
     for (int cc = 0; cc < ncc; ++cc) {
       if (cc > 0) {
         __builtin_amdgcn_s_barrier();  // every wave is done with the previous slice's window
         issue_window(cc);
       }
-      for (int tap = 0; tap < 9; ++tap) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      for (int tap = 0; tap < 9; ++tap, ++tau) {
+        // this step's weights have landed; the window too at tap 0 (it is the youngest request: full drain)
+        if (tap == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else wait_stage(tau + NST - 1 > ntau);
         __builtin_amdgcn_s_barrier();
         if (g.stamps != nullptr && cc == 0 && tap == 0) st1 = (long)__builtin_amdgcn_s_memtime();
-        if (tap < 8) issue((tap + 1) * ncc + cc, buf ^ 1);
-        else if (cc + 1 < ncc) issue(cc + 1, buf ^ 1);
+        {
+          const int ta = tau + NST - 1;  // step whose weights go into the buffer freed by the previous step
+          if (ta < ntau) {
+            const int ca = ta / 9;
+            issue((ta - ca * 9) * ncc + ca, nbuf);
+          }
+        }
         if (wave_active) {
           const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
           const int shift = g.Wd + 1 + dy * g.Wd + dx;
@@ -467,7 +487,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
               }
           }
         }
-        buf ^= 1;
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
       }
     }
   } else {
@@ -484,7 +505,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
         issue(t + NST - 1, nbuf);
         loadA(t + 1);
       }
-      if (wave_active) {
+      if (wave_active && HI16) {  // four k16 steps per stage, one product each
+        const char* const sb = ring + buf * STG;
+  #pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const unsigned so = (unsigned)(((ks * 2 + h) ^ swr) << 4);
+          sp_h8 ah[TM], bh[TN];
+  #pragma unroll
+          for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + so);
+  #pragma unroll
+          for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + so);
+  #pragma unroll
+          for (int j = 0; j < TN; ++j)
+  #pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (wave_active && !HI16) {
         const char* const sb = ring + buf * STG;
   #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {

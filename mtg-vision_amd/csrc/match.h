@@ -18,11 +18,20 @@ class Bank {
   void get_rows(int64_t row, int64_t n, float* out_host) const;
   // thr: results scoring below it are dropped (id -1, score -inf); -INFINITY keeps everything
   void topk(const float* q, int b, int k, int64_t id_base, float thr, int64_t* ids, float* scores, hipStream_t s);
+  // queries of two-pass matches so far whose answer the first pass could not prove and that were scanned exactly
+  // (synchronises the device)
+  int64_t prepass_fallbacks() const;
 
  private:
+  // two-pass match (match.hip): approximate fp16 scores over a hi-only copy of the bank, exact re-rank of the candidates
+  bool prepass_ok(int b, int k) const;
+  void topk_prepass(const float* q, int b, int k, int64_t id_base, float thr, int64_t* ids, float* scores, hipStream_t s);
+  void refresh_hi(int64_t row0, int64_t rows, hipStream_t s);
+
   int dim_;
   int64_t cap_, size_ = 0;
   DevBuf vecs_, qn_, cand_s_, cand_i_;
+  DevBuf hi_, qhi_, stat_;   // fp16 hi halves of the (row-scaled) bank rows / of the normalised queries, 2 bytes per element
 };
 
 void topk_merge_launch_i64(float* cs, const int64_t* ci, int b, int ncand, int k, float thr, int64_t* ids, float* scores,

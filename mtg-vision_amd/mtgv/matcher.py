@@ -100,6 +100,12 @@ class Matcher:
             )
         return ids, scores
 
+    def prepass_fallbacks(self) -> int:
+        """Queries of two-pass matches (>= 128 queries per call) that had to be scanned exactly so far (include/mtgv.h)."""
+        v = native.c_i64(0)
+        native.check(native.lib().mtgv_bank_prepass_fallbacks(self._h, C.byref(v)))
+        return int(v.value)
+
     def __del__(self):
         try:
             if getattr(self, "_h", None) and self._h.value:

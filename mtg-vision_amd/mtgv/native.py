@@ -77,6 +77,7 @@ SIGNATURES = {
     "mtgv_bank_clear": (C.c_int, [c_vp]),
     "mtgv_bank_get_rows": (C.c_int, [c_vp, c_i64, c_i64, c_vp]),
     "mtgv_bank_topk": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp]),
+    "mtgv_bank_prepass_fallbacks": (C.c_int, [c_vp, C.POINTER(c_i64)]),
     "mtgv_topk_merge": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     "mtgv_detector_create": (C.c_int, [C.POINTER(DetectorCfg), C.POINTER(c_vp)]),
     "mtgv_detector_destroy": (None, [c_vp]),

@@ -1,4 +1,6 @@
 """GPU parity of the bank top-k against the brute-force oracle (ids exact; near-ties reported, none tolerated silently)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -140,6 +142,78 @@ def test_exact_ties_in_the_fused_epilogue():
     ids_t, sc_t = m.match(torch.from_numpy(q[7:8]).cuda().repeat(130, 1), 6, threshold=float(sc[7, 0]) - 1e-3)
     assert ids_t[0].tolist() == dup + [-1] and torch.isinf(sc_t[0, 5])
     assert (ids_t == ids_t[0]).all()
+
+
+def _both_paths(m, q, k, **kw):
+    """(two-pass result, one-pass result) of the same query batch"""
+    import os
+
+    old = os.environ.get("MTGV_MATCH_PREPASS")
+    try:
+        os.environ["MTGV_MATCH_PREPASS"] = "1"
+        a = m.match(q, k, **kw)
+        os.environ["MTGV_MATCH_PREPASS"] = "0"
+        b = m.match(q, k, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("MTGV_MATCH_PREPASS", None)
+        else:
+            os.environ["MTGV_MATCH_PREPASS"] = old
+    torch.cuda.synchronize()
+    return a, b
+
+
+@pytest.mark.parametrize("nq,k", [(256, 1), (1024, 3), (131, 4)])
+def test_two_pass_match_equals_one_pass(nq, k):
+    """fp16 first pass + exact re-rank (match.hip) against the one-pass exact kernel on the BASELINE bank: identical ids,
+    scores equal to fp32 rounding (float64 re-rank vs f32 MFMA accumulation)"""
+    from mtgv.matcher import Matcher
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    bank = torch.randn((100_000, 768), generator=g, device="cuda")
+    m = Matcher(768, capacity=100_000)
+    m.add(bank)
+    q = torch.randn((nq, 768), generator=g, device="cuda")
+    pick = torch.randint(0, 100_000, (nq // 2,), generator=g, device="cuda")
+    q[: nq // 2] = bank[pick] + 0.5 * torch.randn((nq // 2, 768), generator=g, device="cuda")
+    (ia, sa), (ib, sb) = _both_paths(m, q, k)
+    os.environ["MTGV_MATCH_PREPASS"] = "0"
+    try:
+        _, s1 = m.match(q, k + 1)  # near-ties: a gap below fp32 accumulation noise anywhere among the best k + 1
+    finally:
+        os.environ.pop("MTGV_MATCH_PREPASS", None)
+    safe = (s1[:, :-1] - s1[:, 1:]).min(1).values > 1e-6
+    assert safe.float().mean() > 0.95
+    assert (ia[safe] == ib[safe]).all()
+    assert (ia[: nq // 2, 0] == pick).all()
+    assert (sa - sb).abs().max().item() < 2e-6
+    # thresholds act on the exact scores in both paths
+    thr = float(sb[:, 0].median())
+    (it, st), (iu, su) = _both_paths(m, q, k, threshold=thr)
+    clear = (sb[:, 0] - thr).abs() > 1e-5
+    assert ((it[:, 0] >= 0) == (iu[:, 0] >= 0))[clear].all()
+    assert (it[:, 0][clear] == iu[:, 0][clear]).all()
+
+
+def test_two_pass_match_falls_back_on_clustered_banks():
+    """more near-duplicates of the best match than the first pass re-ranks: the bound cannot prove the answer, the block
+    scans the bank exactly - ids still equal the one-pass path's (ties by ascending id)"""
+    from mtgv.matcher import Matcher
+
+    g = torch.Generator(device="cuda").manual_seed(4)
+    bank = torch.randn((8192, 768), generator=g, device="cuda")
+    q = torch.randn((130, 768), generator=g, device="cuda")
+    dup = torch.arange(100, 100 + 24 * 200, 200, device="cuda")  # 24 rows spread over the column tiles
+    bank[dup] = q[5] * 2.0 + 1e-4 * torch.randn((24, 768), generator=g, device="cuda")  # within the fp16 noise of each other
+    bank[7000] = q[9]
+    m = Matcher(768, capacity=8192)
+    m.add(bank)
+    (ia, sa), (ib, sb) = _both_paths(m, q, 3)
+    assert set(ia[5].tolist()) <= set(dup.tolist()) and ia[9, 0].item() == 7000
+    # the duplicates' exact scores are separated by ~1e-8: compare as sets where the one-pass scores tie within rounding
+    assert (sa - sb).abs().max().item() < 2e-6
+    rows = [i for i in range(130) if i != 5]
+    assert (ia[rows] == ib[rows]).all()
 
 
 def test_score_threshold_small_batch():
