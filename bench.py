@@ -105,6 +105,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32-roofline", action="store_true", help="skip the extra profiled passes in the f32 operand mode")
+    ap.add_argument("--no-one-stream", action="store_true", help="skip the second timed region (the same steps on one stream)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -227,9 +228,6 @@ def main():
     if not a.no_overlap:
         os.environ.setdefault("MTGV_OVERLAP", "on")
     overlap = (not a.no_overlap) and pipe.overlap_enabled()
-    # the packed-FP32 build of dwconv7_ln is only for one stream per GPU (include/mtgv.h): off while the two streams
-    # overlap and whenever several ranks share one device (rehearsal mode)
-    native.set_packed_fp32(not overlap and not share)
 
     def run_steps(k):
         seq = [batches[i % NB] for i in range(k)]
@@ -285,10 +283,9 @@ def main():
             "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
         },
     }
-    if overlap:
+    if overlap and not a.no_one_stream:
         # the library default (one stream) on the same K steps, timed the same way: `value` is the faster configuration
         # of the two, this is the other one
-        native.set_packed_fp32(not share)  # nothing else shares the GPU with this loop
         pipe.run(batches[0])
         barrier()
         t0 = time.perf_counter()
@@ -300,7 +297,6 @@ def main():
             t = torch.tensor([dt1], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt1 = float(t.item())
-        res["config"]["one_stream_dwconv7_ln"] = "packed-FP32 build" if native.get_packed_fp32() else "plain build"
         res["config"]["one_stream_value"] = round(cards / dt1, 1)
         res["config"]["one_stream_ms_per_step"] = round(dt1 / a.steps * 1e3, 3)
 

@@ -22,9 +22,8 @@ void dwconv7_ln_launch(const float* in, const float* w49, const float* bias, con
 void dwconv7_ln_launch_pk(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b, float* out,
                           int N, int H, int W, int C, float eps, hipStream_t s, int out_fmt);  // rowops_pk.hip
 // May kernels built with packed-FP32 VALU instructions be launched?  They have been seen to lose lanes when a
-// split-precision GEMM of ANOTHER stream (or process) shares the GPU with them, so: yes while
-// the process runs the library on one stream at a time (the default), no with MTGV_OVERLAP=on; MTGV_PACKED_FP32=0|1
-// and mtgv_set_packed_fp32 override.
+// split-precision GEMM of ANOTHER stream (or process) shares the GPU with them, and the one kernel
+// built that way measured slower than its plain build: off unless MTGV_PACKED_FP32=1 or mtgv_set_packed_fp32(1).
 bool packed_fp32_allowed();
 void set_packed_fp32(int allow);
 

@@ -222,13 +222,11 @@ int g_packed = -1;  // -1: not decided yet
 }
 bool packed_fp32_allowed() {
   if (g_packed < 0) {
+    // Off unless asked for: measured on MI355X (profiles/README.md, round 3) the packed build of dwconv7_ln is 19 % SLOWER
+    // than the plain one (80.0 vs 67.3 us per launch, one stream) - halving the stencil's FMA instructions does not
+    // shorten the kernel, so FMA issue is not what it waits on.  Kept selectable for re-measurement on other parts.
     const char* e = getenv("MTGV_PACKED_FP32");
-    if (e != nullptr && *e) {
-      g_packed = atoi(e) != 0 ? 1 : 0;
-    } else {
-      const char* o = getenv("MTGV_OVERLAP");
-      g_packed = (o != nullptr && !strcmp(o, "on")) ? 0 : 1;
-    }
+    g_packed = (e != nullptr && *e && atoi(e) != 0) ? 1 : 0;
   }
   return g_packed == 1;
 }
@@ -244,9 +242,9 @@ void dwconv7_ln_launch(const float* in, const float* w49, const float* bias, con
   MTGV_CHECK(dwconv7_ln_supported(W, C), ERR_INVALID, "dwconv7_ln: unsupported W=%d C=%d", W, C);
   MTGV_CHECK(out_fmt == 0 || C % 8 == 0, ERR_INVALID, "dwconv7_ln: SP8 output needs C=%d %% 8 == 0", C);
   if (N <= 0) return;
-  // The kernel is VALU-bound on its 49-tap stencil.  The packed-FP32 build (rowops_pk.hip) halves the FMA count; it is
-  // used only while the process promises that no split-precision GEMM of another stream shares the GPU with it
-  // (packed_fp32_allowed) - the library default, one stream.  Same FMAs, bit-identical output.
+  // The packed-FP32 build (rowops_pk.hip: v_pk_fma_f32, half the stencil's FMA instructions, bit-identical output) is
+  // opt-in (packed_fp32_allowed): it measured slower than this build, and it may only run while no split-precision GEMM
+  // of another stream shares the GPU.
   if (packed_fp32_allowed())
     dwconv7_ln_launch_pk(in, w49, bias, ln_w, ln_b, out, N, H, W, C, eps, s, out_fmt);
   else

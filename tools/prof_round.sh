@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/two_streams -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/two_streams.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/two_streams -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-one-stream > $OUT/two_streams.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/no_overlap -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-overlap > $OUT/no_overlap.log 2>&1
 for d in two_streams no_overlap; do
   f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1)
