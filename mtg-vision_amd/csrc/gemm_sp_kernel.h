@@ -548,14 +548,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
             bh[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + shi);
             bl[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
           }
+          // small cross terms first, the hi*hi product last (per accumulator); the three products of an accumulator are
+          // issued TM * TN instructions apart, so no MFMA waits on the one just before it
   #pragma unroll
           for (int j = 0; j < TN; ++j)
   #pragma unroll
-            for (int i = 0; i < TM; ++i) {  // small cross terms first, the hi*hi product last
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-            }
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+  #pragma unroll
+          for (int j = 0; j < TN; ++j)
+  #pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+  #pragma unroll
+          for (int j = 0; j < TN; ++j)
+  #pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
         }
       }
       if (AMODE == 1 && t + 1 < nk) storeA(buf ^ 1);
