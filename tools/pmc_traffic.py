@@ -28,5 +28,7 @@ for c in tot:
 kern = {}
 for k in sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"]), key=lambda k: -(2 * tot["FETCH_SIZE"][k] + tot["WRITE_SIZE"][k])):
     kern[k] = {"read_bytes_per_step": int(2 * tot["FETCH_SIZE"][k] * 1024 / steps), "write_bytes_per_step": int(tot["WRITE_SIZE"][k] * 1024 / steps)}
-gemm = sum(kern[k]["read_bytes_per_step"] + kern[k]["write_bytes_per_step"] for k in ("gemm_f32_kernel", "gemm_sp_kernel") if k in kern)
+# the launches bench.py's roofline covers: both GEMM kernels and the fused MLP passes (which do two GEMM layers' work)
+gemm = sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for k, v in kern.items()
+           if k in ("gemm_f32_kernel", "gemm_sp_kernel") or "mlp_fused_kernel" in k)
 print(json.dumps({"precision": tag, "kernels": kern, "hbm_bytes_per_step": gemm}, indent=1))
