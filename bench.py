@@ -106,9 +106,10 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32-roofline", action="store_true", help="skip the extra profiled passes in the f32 operand mode")
     ap.add_argument("--no-one-stream", action="store_true", help="skip the second timed region (the same steps on one stream)")
-    ap.add_argument("--settle-seconds", type=float, default=2.0, help="untimed steady load before the warm-up steps: a freshly leased GPU "
-                    "runs its first few hundred milliseconds of work below its sustained clocks (measured: the first process on a fresh "
-                    "box times 10 %% slower over a 0.2 s region than the same command a minute later)")
+    ap.add_argument("--settle-steps", type=int, default=160, help="untimed steady load before the warm-up steps (a step count, the same on "
+                    "every rank: the sharded match is a collective): a freshly leased GPU can run its first few hundred milliseconds of "
+                    "work below its sustained clocks (one box of round 3 timed a 0.2 s region 10 %% slower as the first process than "
+                    "the same command a minute later)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -240,11 +241,10 @@ def main():
 
     # untimed: bring the freshly leased GPU to its sustained state, then the W warm-up steps the contract asks for
     t_settle = time.perf_counter()
-    settle_steps = 0
-    while time.perf_counter() - t_settle < a.settle_seconds:
-        run_steps(4)
+    for _ in range(0, a.settle_steps, 8):
+        run_steps(8)
         torch.cuda.synchronize()
-        settle_steps += 4
+    t_settle = time.perf_counter() - t_settle
     run_steps(a.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -289,7 +289,7 @@ def main():
             "rest split when a fragment is read), 3 fp16 MFMAs per product, f32 accumulate (error vs fp64 at the f32 level, "
             "tests/test_gpu_precision.py)",
             "streams": "2 (detect of step i+1 beside embed+match of step i; MTGV_OVERLAP=on set by bench.py, the library default is 1)" if overlap else "1",
-            "settle": f"{settle_steps} untimed steps ({a.settle_seconds} s of steady load) before the {a.warmup} warm-up steps",
+            "settle": f"{a.settle_steps} untimed steps ({t_settle:.1f} s of steady load) before the {a.warmup} warm-up steps",
             "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
             "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
         },

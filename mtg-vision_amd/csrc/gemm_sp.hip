@@ -153,6 +153,7 @@ void gemm_sp_launch_cfg1(const SpDev& g, int amode, hipStream_t s);
 void gemm_sp_launch_cfg2(const SpDev& g, int amode, hipStream_t s);
 void gemm_sp_launch_cfg3(const SpDev& g, int amode, hipStream_t s);
 void gemm_sp_launch_cfg4(const SpDev& g, int amode, hipStream_t s);
+void gemm_sp_launch_cfg5(const SpDev& g, int amode, hipStream_t s);
 
 namespace {
 struct SpCfg {
@@ -167,6 +168,7 @@ const SpCfg kCfg[] = {
     {4, 1, 1, 3, 0.88},  // 128 x  96
     {4, 1, 1, 2, 0.80},  // 128 x  64
     {4, 1, 1, 1, 0.62},  // 128 x  32
+    {4, 2, 1, 3, 0.00},  // 128 x 192 on eight waves (swapped in for configuration 1 below; not part of the search)
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -259,6 +261,7 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
   if (best < 0) {
     for (int c = 0; c < kNumCfg; ++c) {
       const SpCfg& k = kCfg[c];
+      if (k.eff <= 0.0) continue;  // not part of the search
       // the 1 KB-per-stage multiplier image of the f32-by-DMA A path does not fit beside the 128 x 192 ring twice per CU
       if (c == 1 && !sp8_in && a.a_scale != nullptr) continue;
       const long tiles = (long)ceil_div(a.M, k.bm()) * ceil_div(a.N, k.bn());
@@ -268,6 +271,11 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
       const double cost = per_cu / k.eff;
       if (best < 0 || cost < best_cost) best = c, best_cost = cost;
     }
+  }
+  {  // eight-wave twin of the 128 x 192 tile (four waves per SIMD) for pwconv1-shaped launches: SP8 rows in, activation
+     // + GRN sums out; measured -3..-4 % on the stage 2-3 layers, nothing on the others (MTGV_SP_CFG8=0: off)
+    static const bool on8 = [] { const char* e = getenv("MTGV_SP_CFG8"); return e == nullptr || atoi(e) != 0; }();
+    if (on8 && best == 1 && !conv && sp8_in && a.grn_part != nullptr && a.topk == 0 && a.K >= 256) best = 5;
   }
   const SpCfg& k = kCfg[best];
   pl.cfg = best;
@@ -422,6 +430,7 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
     case 2: gemm_sp_launch_cfg2(g, amode, s); break;
     case 3: gemm_sp_launch_cfg3(g, amode, s); break;
     case 4: gemm_sp_launch_cfg4(g, amode, s); break;
+    case 5: gemm_sp_launch_cfg5(g, amode, s); break;
     default: MTGV_CHECK(false, ERR_INVALID, "gemm_sp: bad cfg %d", pl.cfg);
   }
   HIP_OK(hipGetLastError());

@@ -85,7 +85,7 @@ typedef const __attribute__((address_space(1))) void* sp_gptr;
 typedef __attribute__((address_space(3))) void* sp_lptr;
 
 template <int WM, int WN, int TM, int TN, int KS, int NST, int AMODE, int ACT, int EPI>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_kernel(const SpDev g) {
 #pragma clang fp contract(off)
   constexpr int NW = WM * WN, NT = 64 * NW, BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr bool GEN = EPI < 0;  // epilogue shape read from the arguments (see the epilogue)
@@ -640,8 +640,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
   // SP8 packing all happen on the read-back side.  Residual rows are loaded one column block ahead.
   constexpr int SROW = 128 * TN;   // bytes per staged row (32*TN floats)
   constexpr int WREG = 32 * SROW;  // per wave
-  static_assert(AWIN || NW * WREG <= NST * STG, "the store staging area must fit into the ring");  // AWIN: the host sizes LDS for it
-  char* const stg = smem + wave * WREG;
+  // Eight-wave blocks (two blocks of them per CU = four waves per SIMD) stage their slabs in two rounds, waves 0..3 first:
+  // the ring holds four slabs, not eight.
+  constexpr int ER = (!AWIN && NW * WREG > NST * STG) ? 2 : 1;
+  static_assert(AWIN || (NW / ER) * WREG <= NST * STG, "the store staging area must fit into the ring");  // AWIN: the host sizes LDS for it
+  char* const stg = smem + (ER == 1 ? wave : wave % (NW / ER)) * WREG;
+  if constexpr (ER == 2) {
+    if (wave >= NW / 2) __builtin_amdgcn_s_barrier();  // released when the first round's waves have read their slabs back
+  }
   constexpr int NIT = 4;              // 8 rows per read-back step
 
   // EPI >= 0 fixes the epilogue's shape at compile time (bit 0 SP8 output, 1 f32 residual, 2 SP8 residual, 3 GRN
@@ -824,6 +830,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_sp_kernel(const SpDev g)
     }
   }
   if (grn) flush();
+  if constexpr (ER == 2) {
+    if (wave < NW / 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
   if (g.stamps != nullptr && wave == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile's stores have been accepted
     const long st3 = (long)__builtin_amdgcn_s_memtime();

@@ -28,7 +28,7 @@ def test_two_ranks_sharded_bench_runs():
         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
         "--frames", "4", "--bank", "20000", "--encoder", "cnvnxt2ae_nano",
     ]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
@@ -45,7 +45,7 @@ def test_bench_launches_its_own_ranks():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4",
            "--bank", "20000", "--encoder", "cnvnxt2ae_nano", "--no-f32-roofline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -59,7 +59,7 @@ def test_sharded_topk_through_rccl_one_rank(tmp_path):
     env = dict(os.environ, MTGV_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "RCCL_ONE_RANK_OK" in r.stdout
 
@@ -69,7 +69,7 @@ def test_bench_one_rank_nccl_forced_collective():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--frames", "4", "--bank", "20000", "--encoder", "cnvnxt2ae_nano", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert res["n_gpus"] == 1 and res["value"] > 0
