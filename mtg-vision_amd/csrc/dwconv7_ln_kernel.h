@@ -49,10 +49,14 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
 #pragma unroll
     for (int j = 0; j < TW; ++j) acc[j] = bv;
+#ifndef DW_DBG
+#define DW_DBG 0  // tools/micro/dwconv_probe.hip: 1 centre row only, 2 loads without the FMAs, 3 no LayerNorm
+#endif
 #pragma unroll 1
     for (int kh = 0; kh < 7; ++kh) {
       const int ih = h + kh - 3;
       if (ih < 0 || ih >= H) continue;
+      if (DW_DBG == 1 && kh != 3) continue;
       const float* rowp = in + ((n * H + ih) * W) * C + c;
       f32x4 r[TW + 6];
 #pragma unroll
@@ -66,7 +70,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
       for (int kw = 0; kw < 7; ++kw) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(w49 + (kh * 7 + kw) * C + c);
 #pragma unroll
-        for (int j = 0; j < TW; ++j) acc[j] += r[j + kw] * wv;
+        for (int j = 0; j < TW; ++j) {
+          if (DW_DBG == 2) acc[j] += (kw == 0 ? r[j] + r[j + 6] : wv);  // keeps every load alive, 1/7 of the arithmetic
+          else acc[j] += r[j + kw] * wv;
+        }
       }
     }
 #pragma unroll
