@@ -15,7 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // per-pixel mean / variance over channels are block-local: partial sums go through LDS in a fixed order
 // (two-pass variance like ln_rows_kernel, deterministic).
 // ---------------------------------------------------------------------------
-template <int TW, bool SP8, int PK>
+template <int TW, bool SP8, int PK, bool WL = false>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ in, const float* __restrict__ w49,
                                                         const float* __restrict__ bias, const float* __restrict__ ln_w,
                                                         const float* __restrict__ ln_b, float* __restrict__ out, int H, int W,
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
   const int c4n = C >> 2;
   float* part = sm;                      // [S][TW][c4n]
   float* stat = sm + S * TW * c4n;       // [S][TW][2] mean, rstd
+  const float* wl = w49;                 // WL: the 49 x C tap table staged in LDS (a third of the kernel's L1 traffic otherwise)
   long blk;
   {
     const long nwg = gridDim.x, b = blockIdx.x;
@@ -31,6 +32,12 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
   }
   const int tid = threadIdx.x;
+  if (WL) {
+    float* wdst = stat + ((S * TW * 2 + 3) & ~3);
+    for (int i = tid; i < 49 * c4n; i += 256) reinterpret_cast<f32x4*>(wdst)[i] = reinterpret_cast<const f32x4*>(w49)[i];
+    wl = wdst;
+    __syncthreads();
+  }
   const int sl = tid / c4n, c4 = tid % c4n;  // strip slot in block, channel quad
   const long strip = blk * S + sl;
   const bool live = sl < S && strip < total_strips;
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
       }
 #pragma unroll
       for (int kw = 0; kw < 7; ++kw) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w49 + (kh * 7 + kw) * C + c);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (kh * 7 + kw) * C + c);
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
           if (DW_DBG == 2) acc[j] += (kw == 0 ? r[j] + r[j + 6] : wv);  // keeps every load alive, 1/7 of the arithmetic
@@ -121,9 +128,161 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
 }
 
 
+// Row-group form of the same kernel: a thread keeps TH output rows of its TW-pixel strip in registers and walks the TH + 6
+// input rows once, so an input row is fetched (TH + 6) / TH times instead of 7 (tools/micro/dwconv_probe.hip: the six
+// extra row fetches, not the FMAs, are 45 % of the single-row kernel's time at stage 0).  Every output still accumulates
+// bias, then kh ascending, kw ascending: bit-identical to dwconv7_ln_kernel.
+template <int TW, int TH, bool SP8, bool WL = false>
+__global__ __launch_bounds__(256) void dwconv7_ln_rows_kernel(const float* __restrict__ in, const float* __restrict__ w49,
+                                                             const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                             const float* __restrict__ ln_b, float* __restrict__ out, int H, int W,
+                                                             int C, int nstrips, int nhg, long total_strips, int S, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int P = TH * TW;             // pixels a thread owns
+  const int c4n = C >> 2;
+  float* part = sm;                      // [S][P][c4n]
+  float* stat = sm + S * P * c4n;        // [S][P][2] mean, rstd
+  const float* wl = w49;
+  const int tid = threadIdx.x;
+  if (WL) {
+    float* wdst = stat + ((S * P * 2 + 3) & ~3);
+    for (int i = tid; i < 49 * c4n; i += 256) reinterpret_cast<f32x4*>(wdst)[i] = reinterpret_cast<const f32x4*>(w49)[i];
+    wl = wdst;
+    __syncthreads();
+  }
+  const int sl = tid / c4n, c4 = tid % c4n;
+  const int c = c4 * 4;
+  long blk;
+  {
+    const long nwg = gridDim.x, b = blockIdx.x;
+    const long q = nwg >> 3, r = nwg & 7, x = b & 7;
+    blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  const long strip = blk * S + sl;
+  const bool live = sl < S && strip < total_strips;
+  int ws = 0, h0 = 0;
+  long n = 0;
+  if (live) {
+    ws = (int)(strip % nstrips);
+    const long t = strip / nstrips;
+    h0 = (int)(t % nhg) * TH;
+    n = t / nhg;
+  }
+  const int w0 = ws * TW;
+  f32x4 acc[TH][TW];
+  if (live) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+    for (int t = 0; t < TH; ++t)
+#pragma unroll
+      for (int j = 0; j < TW; ++j) acc[t][j] = bv;
+#pragma unroll 1
+    for (int ir = 0; ir < TH + 6; ++ir) {
+      const int ih = h0 + ir - 3;
+      if (ih < 0 || ih >= H) continue;
+      const float* rowp = in + ((n * H + ih) * W) * C + c;
+      f32x4 r[TW + 6];
+#pragma unroll
+      for (int j = 0; j < TW + 6; ++j) {
+        const int iw = w0 + j - 3;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iw >= 0 && iw < W) v = *reinterpret_cast<const f32x4*>(rowp + (long)iw * C);
+        r[j] = v;
+      }
+#pragma unroll
+      for (int t = 0; t < TH; ++t) {
+        const int kh = ir - t;  // output row h0 + t sees this input row as its tap row kh
+        if (kh < 0 || kh > 6) continue;
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (kh * 7 + kw) * C + c);
+#pragma unroll
+          for (int j = 0; j < TW; ++j) acc[t][j] += r[j + kw] * wv;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TH; ++t)
+#pragma unroll
+      for (int j = 0; j < TW; ++j)
+        part[(sl * P + t * TW + j) * c4n + c4] = (acc[t][j][0] + acc[t][j][1]) + (acc[t][j][2] + acc[t][j][3]);
+  }
+  __syncthreads();
+  if (live)
+    for (int p = c4; p < P; p += c4n) {  // thread c4 of a strip reduces pixels c4, c4 + c4n, ...
+      const float* pp = part + (sl * P + p) * c4n;
+      float sum = 0.f;
+      for (int i = 0; i < c4n; ++i) sum += pp[i];
+      stat[(sl * P + p) * 2] = sum / (float)C;
+    }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < TH; ++t)
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        const f32x4 d = acc[t][j] - stat[(sl * P + t * TW + j) * 2];
+        part[(sl * P + t * TW + j) * c4n + c4] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+  }
+  __syncthreads();
+  if (live)
+    for (int p = c4; p < P; p += c4n) {
+      const float* pp = part + (sl * P + p) * c4n;
+      float sq = 0.f;
+      for (int i = 0; i < c4n; ++i) sq += pp[i];
+      stat[(sl * P + p) * 2 + 1] = 1.0f / sqrtf(sq / (float)C + eps);
+    }
+  __syncthreads();
+  if (live) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(ln_w + c);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(ln_b + c);
+#pragma unroll
+    for (int t = 0; t < TH; ++t) {
+      if (h0 + t >= H) continue;
+      float* op = out + ((n * H + h0 + t) * W + w0) * C + c;
+#pragma unroll
+      for (int j = 0; j < TW; ++j)
+        if (w0 + j < W) {
+          const float mean = stat[(sl * P + t * TW + j) * 2], rstd = stat[(sl * P + t * TW + j) * 2 + 1];
+          const f32x4 o = (acc[t][j] - mean) * rstd * wv + bv;
+          if (SP8)
+            *reinterpret_cast<sp_h8*>(reinterpret_cast<char*>(op + (long)j * C - c) + (c4 >> 1) * 32 + (c4 & 1) * 16) =
+                sp8_piece_from_quad(o, c4);
+          else
+            *reinterpret_cast<f32x4*>(op + (long)j * C) = o;
+        }
+    }
+  }
+}
+
+template <int TW, int TH, bool SP8, bool WL = false>
+static void dwconv7_ln_rows_launch(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b,
+                                   float* out, int N, int H, int W, int C, float eps, hipStream_t s) {
+  const int nstrips = ceil_div(W, TW), nhg = ceil_div(H, TH);
+  const int c4n = C / 4;
+  const int S = 256 / c4n;
+  const long total_strips = (long)N * nhg * nstrips;
+  const unsigned grid = (unsigned)((total_strips + S - 1) / S);
+  const size_t lds = (size_t)(S * TH * TW * (c4n + 2) + 4 + (WL ? 49 * C : 0)) * sizeof(float);
+  if (lds > 65536) throw Error(ERR_RUNTIME, "dwconv7_ln_rows: the tap table does not fit the default LDS window");
+  hipLaunchKernelGGL((dwconv7_ln_rows_kernel<TW, TH, SP8, WL>), dim3(grid), dim3(256), lds, s, in, w49, bias, ln_w, ln_b, out, H, W, C,
+                     nstrips, nhg, total_strips, S, eps);
+  HIP_OK(hipGetLastError());
+}
+
 template <int PK>
 static void dwconv7_ln_launch_t(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b,
                                 float* out, int N, int H, int W, int C, float eps, hipStream_t s, int out_fmt) {
+  // Narrow layers (the first stage): three output rows per thread and the tap table in LDS, 126.6 us against 154.3 us on
+  // 256 x 48 x 32 x 96 (tools/micro/dwconv_rows_probe.hip); wider layers measured no better that way.
+  static const bool rows_on = !(getenv("MTGV_DW_ROWS") && atoi(getenv("MTGV_DW_ROWS")) == 0);
+  if constexpr (PK == 0)  // the rows kernel is not keyed by PK: only the TU built without packed FP32 may instantiate it
+  if (rows_on && C <= 96 && W >= 4 && H >= 3) {
+    if (out_fmt == 1) dwconv7_ln_rows_launch<4, 3, true, true>(in, w49, bias, ln_w, ln_b, out, N, H, W, C, eps, s);
+    else dwconv7_ln_rows_launch<4, 3, false, true>(in, w49, bias, ln_w, ln_b, out, N, H, W, C, eps, s);
+    return;
+  }
   const int tw = W >= 8 ? 8 : (W >= 4 ? 4 : 2);
   const int nstrips = ceil_div(W, tw);
   const int c4n = C / 4;
