@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
                                                         int C, int nstrips, long total_strips, int S, float eps) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int c4n = C >> 2;
-  float* part = sm;                      // [S][TW][c4n]
+  float* part = sm;                      // [S][c4n][TW]: a pixel's partial sums sit TW floats apart, so the lanes that reduce
+                                         // pixels 0..TW-1 read consecutive words (no bank conflicts) in the same c4 order
   float* stat = sm + S * TW * c4n;       // [S][TW][2] mean, rstd
   const float* wl = w49;                 // WL: the 49 x C tap table staged in LDS (a third of the kernel's L1 traffic otherwise)
   long blk;
@@ -84,13 +85,13 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
       }
     }
 #pragma unroll
-    for (int j = 0; j < TW; ++j) part[(sl * TW + j) * c4n + c4] = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+    for (int j = 0; j < TW; ++j) part[(sl * c4n + c4) * TW + j] = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
   }
   __syncthreads();
   if (live && c4 < TW) {  // thread c4 of a strip reduces pixel j = c4
-    const float* pp = part + (sl * TW + c4) * c4n;
+    const float* pp = part + sl * c4n * TW + c4;
     float sum = 0.f;
-    for (int i = 0; i < c4n; ++i) sum += pp[i];
+    for (int i = 0; i < c4n; ++i) sum += pp[i * TW];
     stat[(sl * TW + c4) * 2] = sum / (float)C;
   }
   __syncthreads();
@@ -98,14 +99,14 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < TW; ++j) {
       const f32x4 d = acc[j] - stat[(sl * TW + j) * 2];
-      part[(sl * TW + j) * c4n + c4] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      part[(sl * c4n + c4) * TW + j] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
     }
   }
   __syncthreads();
   if (live && c4 < TW) {
-    const float* pp = part + (sl * TW + c4) * c4n;
+    const float* pp = part + sl * c4n * TW + c4;
     float sq = 0.f;
-    for (int i = 0; i < c4n; ++i) sq += pp[i];
+    for (int i = 0; i < c4n; ++i) sq += pp[i * TW];
     stat[(sl * TW + c4) * 2 + 1] = 1.0f / sqrtf(sq / (float)C + eps);
   }
   __syncthreads();
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_rows_kernel(const float* __res
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int P = TH * TW;             // pixels a thread owns
   const int c4n = C >> 2;
-  float* part = sm;                      // [S][P][c4n]
+  float* part = sm;                      // [S][c4n][P]
   float* stat = sm + S * P * c4n;        // [S][P][2] mean, rstd
   const float* wl = w49;
   const int tid = threadIdx.x;
@@ -205,14 +206,14 @@ __global__ __launch_bounds__(256) void dwconv7_ln_rows_kernel(const float* __res
     for (int t = 0; t < TH; ++t)
 #pragma unroll
       for (int j = 0; j < TW; ++j)
-        part[(sl * P + t * TW + j) * c4n + c4] = (acc[t][j][0] + acc[t][j][1]) + (acc[t][j][2] + acc[t][j][3]);
+        part[(sl * c4n + c4) * P + t * TW + j] = (acc[t][j][0] + acc[t][j][1]) + (acc[t][j][2] + acc[t][j][3]);
   }
   __syncthreads();
   if (live)
     for (int p = c4; p < P; p += c4n) {  // thread c4 of a strip reduces pixels c4, c4 + c4n, ...
-      const float* pp = part + (sl * P + p) * c4n;
+      const float* pp = part + sl * c4n * P + p;
       float sum = 0.f;
-      for (int i = 0; i < c4n; ++i) sum += pp[i];
+      for (int i = 0; i < c4n; ++i) sum += pp[i * P];
       stat[(sl * P + p) * 2] = sum / (float)C;
     }
   __syncthreads();
@@ -222,15 +223,15 @@ __global__ __launch_bounds__(256) void dwconv7_ln_rows_kernel(const float* __res
 #pragma unroll
       for (int j = 0; j < TW; ++j) {
         const f32x4 d = acc[t][j] - stat[(sl * P + t * TW + j) * 2];
-        part[(sl * P + t * TW + j) * c4n + c4] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        part[(sl * c4n + c4) * P + t * TW + j] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
       }
   }
   __syncthreads();
   if (live)
     for (int p = c4; p < P; p += c4n) {
-      const float* pp = part + (sl * P + p) * c4n;
+      const float* pp = part + sl * c4n * P + p;
       float sq = 0.f;
-      for (int i = 0; i < c4n; ++i) sq += pp[i];
+      for (int i = 0; i < c4n; ++i) sq += pp[i * P];
       stat[(sl * P + p) * 2 + 1] = 1.0f / sqrtf(sq / (float)C + eps);
     }
   __syncthreads();
@@ -265,7 +266,14 @@ static void dwconv7_ln_rows_launch(const float* in, const float* w49, const floa
   const long total_strips = (long)N * nhg * nstrips;
   const unsigned grid = (unsigned)((total_strips + S - 1) / S);
   const size_t lds = (size_t)(S * TH * TW * (c4n + 2) + 4 + (WL ? 49 * C : 0)) * sizeof(float);
-  if (lds > 65536) throw Error(ERR_RUNTIME, "dwconv7_ln_rows: the tap table does not fit the default LDS window");
+  if (lds > 65536) {  // (not reached by the library's own launches: C <= 96)
+    static bool attr[MTGV_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!attr[dev]) {
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv7_ln_rows_kernel<TW, TH, SP8, WL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr[dev] = true;
+    }
+  }
   hipLaunchKernelGGL((dwconv7_ln_rows_kernel<TW, TH, SP8, WL>), dim3(grid), dim3(256), lds, s, in, w49, bias, ln_w, ln_b, out, H, W, C,
                      nstrips, nhg, total_strips, S, eps);
   HIP_OK(hipGetLastError());
@@ -274,13 +282,22 @@ static void dwconv7_ln_rows_launch(const float* in, const float* w49, const floa
 template <int PK>
 static void dwconv7_ln_launch_t(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b,
                                 float* out, int N, int H, int W, int C, float eps, hipStream_t s, int out_fmt) {
-  // Narrow layers (the first stage): three output rows per thread and the tap table in LDS, 126.6 us against 154.3 us on
-  // 256 x 48 x 32 x 96 (tools/micro/dwconv_rows_probe.hip); wider layers measured no better that way.
+  // Row-group forms (tools/micro/dwconv_rows_probe.hip, profiles/r03_dwconv_rows_probe.txt; all bit-identical to the
+  // single-row kernel): 4-pixel strips x 3 rows with the tap table in LDS while table + partial sums fit the default
+  // 64 KB window (C <= 192: 121.5 vs 144-155 us at 256 x 48 x 32 x 96, 60.9 vs 66.7 at 24 x 16 x 192), else 3 rows of the
+  // widest strip (34.7 vs 38.6 us at 12 x 8 x 384, 20.3 vs 24.7 at 6 x 4 x 768).  MTGV_DW_ROWS=0: single-row kernel.
   static const bool rows_on = !(getenv("MTGV_DW_ROWS") && atoi(getenv("MTGV_DW_ROWS")) == 0);
   if constexpr (PK == 0)  // the rows kernel is not keyed by PK: only the TU built without packed FP32 may instantiate it
-  if (rows_on && C <= 96 && W >= 4 && H >= 3) {
-    if (out_fmt == 1) dwconv7_ln_rows_launch<4, 3, true, true>(in, w49, bias, ln_w, ln_b, out, N, H, W, C, eps, s);
-    else dwconv7_ln_rows_launch<4, 3, false, true>(in, w49, bias, ln_w, ln_b, out, N, H, W, C, eps, s);
+  if (rows_on && W >= 4) {
+    const int c4n_ = C / 4, S_ = 256 / c4n_;
+    const bool table = (size_t)(S_ * 12 * (c4n_ + 2) + 4 + 49 * C) * sizeof(float) <= 65536;
+#define DWROWS_GO(TW_, WL_)                                                                                          \
+  (out_fmt == 1 ? dwconv7_ln_rows_launch<TW_, 3, true, WL_>(in, w49, bias, ln_w, ln_b, out, N, H, W, C, eps, s)        \
+                : dwconv7_ln_rows_launch<TW_, 3, false, WL_>(in, w49, bias, ln_w, ln_b, out, N, H, W, C, eps, s))
+    if (table) DWROWS_GO(4, true);
+    else if (W >= 8) DWROWS_GO(8, false);
+    else DWROWS_GO(4, false);
+#undef DWROWS_GO
     return;
   }
   const int tw = W >= 8 ? 8 : (W >= 4 ? 4 : 2);
