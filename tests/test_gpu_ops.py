@@ -149,9 +149,10 @@ def test_block_vs_oracle(n, h, w, c, act):
     assert (got - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("n,h,w,c", [(3, 48, 32, 96), (2, 12, 8, 384), (2, 28, 28, 192)])
+@pytest.mark.parametrize("n,h,w,c", [(3, 48, 32, 96), (2, 12, 8, 384), (2, 28, 28, 192), (2, 7, 7, 768), (1, 14, 14, 384), (1, 5, 9, 80), (2, 6, 4, 768)])
 def test_packed_fp32_build_of_dwconv_ln_is_bit_identical(n, h, w, c):
-    """the packed-FP32 build of dwconv7_ln (one-stream default) and the plain build give the same bits (whole block)"""
+    """the packed-FP32 build of dwconv7_ln (the single-row kernel) and the plain build (the row-group kernels: three output
+    rows per thread, ragged last rows and strips included) give the same bits (whole block)"""
     nv = _lib()
     rng = np.random.default_rng(c)
     f = lambda *sh: _dev(rng.standard_normal(sh).astype(np.float32) * 0.3)  # noqa: E731
