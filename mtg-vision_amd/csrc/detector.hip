@@ -172,21 +172,35 @@ __global__ __launch_bounds__(256) void conv0_u8_kernel(const uint8_t* __restrict
   for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int o = 0; o < 16; ++o) acc[p][o] = ws[16 * 9 * 4 + o];
-  const int c0 = flip ? 2 : 0, c2 = flip ? 0 : 2;
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int ih = 2 * oh - 1 + kh;
     if (ih < 0 || ih >= S) continue;
     const uint8_t* const rowp = frames + ((n * S + ih) * (long)S) * 3;
     float x[9][3];  // input columns 2*ow0-1 .. 2*ow0+7
+    // The nine pixels are bytes 24 q - 3 .. 24 q + 23 of the row: one dword for the pixel left of the strip (zero padding
+    // at q == 0 - the only column that can fall outside, S = 8 OQ) and three aligned 8-byte loads for the other eight.
+    uint32_t d[7];
+    d[0] = q > 0 ? *reinterpret_cast<const uint32_t*>(rowp + 24 * q - 4) : 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint2 v = *reinterpret_cast<const uint2*>(rowp + 24 * q + 8 * k);
+      d[1 + 2 * k] = v.x, d[2 + 2 * k] = v.y;
+    }
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-      const int iw = 2 * ow0 - 1 + j;
-      const bool ok = iw >= 0 && iw < S;
-      const uint8_t* const px = rowp + (long)(ok ? iw : 0) * 3;
-      x[j][0] = ok ? __fdiv_rn((float)px[c0], 255.0f) : 0.f;
-      x[j][1] = ok ? __fdiv_rn((float)px[1], 255.0f) : 0.f;
-      x[j][2] = ok ? __fdiv_rn((float)px[c2], 255.0f) : 0.f;
+      float b[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const int k = 1 + 3 * j + ch;  // byte index in d[]
+        const float u = (float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu);  // v_cvt_f32_ubyteN
+        // u / 255 correctly rounded without the division sequence: one Newton step on u * fl(1/255) gives the IEEE
+        // quotient for every byte value (tests/test_oracle_detector_cpu.py checks all 256 against exact rational arithmetic)
+        const float r255 = 1.0f / 255.0f;
+        const float q0 = u * r255;
+        b[ch] = __builtin_fmaf(__builtin_fmaf(-q0, 255.0f, u), r255, q0);
+      }
+      x[j][0] = flip ? b[2] : b[0], x[j][1] = b[1], x[j][2] = flip ? b[0] : b[2];
     }
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
@@ -651,6 +665,7 @@ void Detector::conv0(const uint8_t* frames, int n, int flip, hipStream_t s) {
     const View l0 = view("l0");
     const long total = (long)n * (S / 2) * (S / 8);
     MTGV_CHECK((S / 2) % 4 == 0 && w0.cout == 16 && w0.cin == 4 && w0.k == 3, ERR_RUNTIME, "detector: unexpected model.0 geometry");
+    MTGV_CHECK(((uintptr_t)frames & 7) == 0, ERR_INVALID, "detector: the frame buffer must be 8-byte aligned");
     if (fmt_ == 1)
       hipLaunchKernelGGL((conv0_u8_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, w0.w, w0.b, l0.p, S, flip, total);
     else

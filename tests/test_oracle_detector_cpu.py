@@ -149,3 +149,23 @@ def test_detector_config_for_state_picks_family_and_nc():
         sd = spec.random_detector_state(cfg, 0)
         got = spec.detector_config_for_state(sd)
         assert got.arch == cfg.arch and got.nc == cfg.nc and got.depth == cfg.depth
+
+
+def test_byte_over_255_without_a_division_is_the_ieee_quotient():
+    """conv0_u8_kernel (csrc/detector.hip) turns a frame byte u into u / 255 (ultralytics preprocess, img / 255) as
+    q = u * fl(1/255); q' = fma(fma(-q, 255, u), fl(1/255), q).  Checked here for all 256 bytes against the correctly
+    rounded quotient, with the two fused operations evaluated in exact rational arithmetic."""
+    from fractions import Fraction
+
+    def rnd32(fr):
+        f = np.float32(float(fr))
+        cands = [np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))]
+        return np.float32(min(cands, key=lambda c: (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1)))
+
+    r = np.float32(1.0) / np.float32(255.0)
+    for u in range(256):
+        ref = np.float32(u) / np.float32(255.0)
+        q = np.float32(u) * r
+        e = rnd32(Fraction(u) - Fraction(float(q)) * 255)
+        q2 = rnd32(Fraction(float(e)) * Fraction(float(r)) + Fraction(float(q)))
+        assert q2 == ref, u
