@@ -4,7 +4,7 @@
 //   warp_coeffs_kernel  one thread per quad: the 8x8 system of the homography that maps the
 //                       output rectangle (expanded by expand_ratio) onto the source quad,
 //                       Gaussian elimination with partial pivoting in float64
-//   warp_kernel         one thread per output pixel: projective map, 1/32-pixel quantised
+//   warp_kernel         one thread per (group of four) output pixel(s): projective map, 1/32-pixel quantised
 //                       source position, 4-tap bilinear with 15-bit fixed-point weights
 //
 // The sub-pixel quantisation and fixed-point blend restate what OpenCV's INTER_LINEAR remap
@@ -81,54 +81,105 @@ __device__ __forceinline__ int sat_short_rint(float v) {
   return r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
 }
 
+// PX output pixels of a row per thread (PX = 4 when out_w % 4 == 0 and the buffers are 4-byte aligned: the 12 output bytes
+// leave as three dwords; PX = 1 otherwise).  Taps whose 2 x 2 window lies inside the frame are fetched as three aligned
+// dwords per row (the six bytes of two neighbouring pixels start at any byte offset) instead of six byte loads; windows
+// that touch the border take the byte path with constant border 0.  The arithmetic per pixel is the same in every path.
+template <int PX>
 __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ frames, int fh, int fw,
                                                   const double* __restrict__ coef, const int* __restrict__ frame_idx, int nq,
                                                   int out_h, int out_w, uint8_t* __restrict__ out) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long gidx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long idx = gidx * PX;  // first output pixel of this thread
   const long total = (long)nq * out_h * out_w;
   if (idx >= total) return;
-  const int x = (int)(idx % out_w);
+  const int x0 = (int)(idx % out_w);
   const long t = idx / out_w;
   const int y = (int)(t % out_h);
   const int q = (int)(t / out_h);
   const double* c = coef + (long)q * 9;
-  const double X0 = c[0] * (double)x + c[1] * (double)y + c[2];
-  const double Y0 = c[3] * (double)x + c[4] * (double)y + c[5];
-  double W = c[6] * (double)x + c[7] * (double)y + c[8];
-  W = W != 0.0 ? 32.0 / W : 0.0;
-  const double fX = fmax(-2147483648.0, fmin(2147483647.0, X0 * W));
-  const double fY = fmax(-2147483648.0, fmin(2147483647.0, Y0 * W));
-  const int X = (int)rint(fX), Y = (int)rint(fY);
-  const int sx = X >> 5, sy = Y >> 5;
-  const float fx = (float)(X & 31) / 32.0f, fy = (float)(Y & 31) / 32.0f;
-  // 15-bit weights, sum forced to 1 << 15 by adjusting the largest tap
-  int wq[4];
-  wq[0] = sat_short_rint((1.0f - fy) * (1.0f - fx) * 32768.0f);
-  wq[1] = sat_short_rint((1.0f - fy) * fx * 32768.0f);
-  wq[2] = sat_short_rint(fy * (1.0f - fx) * 32768.0f);
-  wq[3] = sat_short_rint(fy * fx * 32768.0f);
-  int big = 0;
-  for (int i = 1; i < 4; ++i)
-    if (wq[i] > wq[big]) big = i;
-  wq[big] += 32768 - (wq[0] + wq[1] + wq[2] + wq[3]);
-
   const uint8_t* F = frames + (long)frame_idx[q] * fh * fw * 3;
-  int acc[3] = {0, 0, 0};
+  const long frame_px = (long)fh * fw;
+  uint32_t pix[PX];  // b | g << 8 | r << 16 in memory order: three result bytes per pixel
 #pragma unroll
-  for (int tap = 0; tap < 4; ++tap) {
-    const int px = sx + (tap & 1), py = sy + (tap >> 1);
-    if (px >= 0 && px < fw && py >= 0 && py < fh) {
-      const uint8_t* p = F + ((long)py * fw + px) * 3;
-      acc[0] += wq[tap] * (int)p[0];
-      acc[1] += wq[tap] * (int)p[1];
-      acc[2] += wq[tap] * (int)p[2];
+  for (int j = 0; j < PX; ++j) {
+    const int x = x0 + j;
+    const double X0 = c[0] * (double)x + c[1] * (double)y + c[2];
+    const double Y0 = c[3] * (double)x + c[4] * (double)y + c[5];
+    double W = c[6] * (double)x + c[7] * (double)y + c[8];
+    W = W != 0.0 ? 32.0 / W : 0.0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, X0 * W));
+    const double fY = fmax(-2147483648.0, fmin(2147483647.0, Y0 * W));
+    const int X = (int)rint(fX), Y = (int)rint(fY);
+    const int sx = X >> 5, sy = Y >> 5;
+    const float fx = (float)(X & 31) / 32.0f, fy = (float)(Y & 31) / 32.0f;
+    // 15-bit weights, sum forced to 1 << 15 by adjusting the largest tap
+    int wq[4];
+    wq[0] = sat_short_rint((1.0f - fy) * (1.0f - fx) * 32768.0f);
+    wq[1] = sat_short_rint((1.0f - fy) * fx * 32768.0f);
+    wq[2] = sat_short_rint(fy * (1.0f - fx) * 32768.0f);
+    wq[3] = sat_short_rint(fy * fx * 32768.0f);
+    int big = 0;
+    for (int i = 1; i < 4; ++i)
+      if (wq[i] > wq[big]) big = i;
+    wq[big] += 32768 - (wq[0] + wq[1] + wq[2] + wq[3]);
+
+    int acc[3] = {0, 0, 0};
+    const long p00 = (long)sy * fw + sx;  // pixel index of the top-left tap
+    if (sx >= 0 && sy >= 0 && sx + 1 < fw && sy + 1 < fh && p00 + fw + 4 <= frame_px) {
+      // both rows: bytes [3 p, 3 p + 6) out of the aligned 12-byte window that starts at (3 p) & ~3
+#pragma unroll
+      for (int row = 0; row < 2; ++row) {
+        const long B = (p00 + (long)row * fw) * 3;
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(F + (B & ~3L));
+        const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
+        const int sh = (int)(B & 3) * 8;
+        const uint64_t lo = ((uint64_t)d1 << 32) | d0, hi = ((uint64_t)d2 << 32) | d1;
+        const uint32_t b03 = (uint32_t)(lo >> sh), b47 = (uint32_t)(hi >> sh);  // bytes 0..3 and 4..7 from B
+        const int wl = wq[row * 2], wr = wq[row * 2 + 1];
+        acc[0] += wl * (int)(b03 & 0xff);
+        acc[1] += wl * (int)((b03 >> 8) & 0xff);
+        acc[2] += wl * (int)((b03 >> 16) & 0xff);
+        acc[0] += wr * (int)(b03 >> 24);
+        acc[1] += wr * (int)(b47 & 0xff);
+        acc[2] += wr * (int)((b47 >> 8) & 0xff);
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < 4; ++tap) {
+        const int px = sx + (tap & 1), py = sy + (tap >> 1);
+        if (px >= 0 && px < fw && py >= 0 && py < fh) {
+          const uint8_t* p = F + ((long)py * fw + px) * 3;
+          acc[0] += wq[tap] * (int)p[0];
+          acc[1] += wq[tap] * (int)p[1];
+          acc[2] += wq[tap] * (int)p[2];
+        }
+      }
     }
+    uint32_t pk = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      int v = (acc[ch] + (1 << 14)) >> 15;
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+#if defined(__HIP_DEVICE_COMPILE__)
+      // Opaque to the optimiser on purpose: two of these next to each other are otherwise fused into v_ashr_pk_u8_i32,
+      // and on gfx950 the upper half of that instruction's result is not the zero its selection pattern assumes (the
+      // stale bits of the first operand showed up in every fourth pixel; tools/debug/warp_px_probe.py).
+      asm volatile("" : "+v"(v));
+#endif
+      pk |= (uint32_t)v << (8 * ch);
+    }
+    pix[j] = pk;
   }
   uint8_t* o = out + idx * 3;
+  if constexpr (PX == 4) {
+    uint32_t* ow = reinterpret_cast<uint32_t*>(o);
+    ow[0] = pix[0] | (pix[1] << 24);
+    ow[1] = (pix[1] >> 8) | (pix[2] << 16);
+    ow[2] = (pix[2] >> 16) | (pix[3] << 8);
+  } else {
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    int v = (acc[ch] + (1 << 14)) >> 15;
-    o[ch] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    for (int ch = 0; ch < 3; ++ch) o[ch] = (uint8_t)(pix[0] >> (8 * ch));
   }
 }
 
@@ -188,8 +239,14 @@ MTGV_API int mtgv_warp_quads(const uint8_t* frames_dev, int32_t nf, int32_t fh, 
     hipLaunchKernelGGL(warp_coeffs_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, quads_dev, nq, out_h, out_w, expand_ratio, coef);
     HIP_OK(hipGetLastError());
     const long total = (long)nq * out_h * out_w;
-    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames_dev, fh, fw, coef, frame_idx_dev,
-                       nq, out_h, out_w, out_dev);
+    // four pixels per thread need rows of whole groups and dword-aligned buffers (frame f starts at f * fh * fw * 3 bytes)
+    static const bool px1 = getenv("MTGV_WARP_PX1") != nullptr;  // debugging aid: one pixel per thread
+    if (!px1 && out_w % 4 == 0 && ((uintptr_t)out_dev & 3) == 0 && ((uintptr_t)frames_dev & 3) == 0 && ((long)fh * fw * 3) % 4 == 0)
+      hipLaunchKernelGGL(warp_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, frames_dev, fh, fw, coef, frame_idx_dev,
+                         nq, out_h, out_w, out_dev);
+    else
+      hipLaunchKernelGGL(warp_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames_dev, fh, fw, coef, frame_idx_dev,
+                         nq, out_h, out_w, out_dev);
     HIP_OK(hipGetLastError());
   });
 }
