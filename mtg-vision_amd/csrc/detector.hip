@@ -160,8 +160,13 @@ __global__ __launch_bounds__(256) void conv0_u8_kernel(const uint8_t* __restrict
   if (threadIdx.x < 16) ws[16 * 9 * 4 + threadIdx.x] = bias[threadIdx.x];
   __syncthreads();
   const int OS = S >> 1, OQ = OS >> 2;  // output size, groups of 4 output columns per row
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over n * OS * OQ
-  if (idx >= total) return;
+  // Output staging: a thread's four pixels are 256 contiguous bytes and thread i + 1 continues where thread i ends, so
+  // a store issued by every lane for its own piece would touch 64 different lines.  Each wave passes its pieces through
+  // LDS (two pixels = 8 pieces of 16 B per thread at a time, rows padded to 144 B) and stores them back transposed:
+  // eight lanes write one thread's 128 bytes, a store instruction writes eight whole lines.
+  __shared__ __attribute__((aligned(16))) f32x4 stage[4][64][9];
+  const long idx_raw = (long)blockIdx.x * 256 + threadIdx.x;  // over n * OS * OQ
+  const long idx = idx_raw < total ? idx_raw : total - 1;     // (threads past the end compute a duplicate and store nothing)
   const int q = (int)(idx % OQ);
   const long t = idx / OQ;
   const int oh = (int)(t % OS);
@@ -217,21 +222,33 @@ __global__ __launch_bounds__(256) void conv0_u8_kernel(const uint8_t* __restrict
         }
       }
   }
-  float* const orow = out + ((n * OS + oh) * (long)OS + ow0) * 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long wave_idx0 = (long)blockIdx.x * 256 + wave * 64;  // output is contiguous in idx order: 64 floats per thread
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    f32x4 v[4];
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int o = 0; o < 16; ++o) v[o >> 2][o & 3] = act_silu(acc[p][o]);
-    if (SP8) {
-      sp_h8 hi, lo;
-      sp8_split8(v[0], v[1], hi, lo);
-      reinterpret_cast<sp_h8*>(orow + p * 16)[0] = hi, reinterpret_cast<sp_h8*>(orow + p * 16)[1] = lo;
-      sp8_split8(v[2], v[3], hi, lo);
-      reinterpret_cast<sp_h8*>(orow + p * 16)[2] = hi, reinterpret_cast<sp_h8*>(orow + p * 16)[3] = lo;
-    } else {
+    for (int pp = 0; pp < 2; ++pp) {
+      const int p = half * 2 + pp;
+      f32x4 v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) reinterpret_cast<f32x4*>(orow + p * 16)[k] = v[k];
+      for (int o = 0; o < 16; ++o) v[o >> 2][o & 3] = act_silu(acc[p][o]);
+      if (SP8) {
+        sp_h8 hi, lo;
+        sp8_split8(v[0], v[1], hi, lo);
+        stage[wave][lane][pp * 4 + 0] = __builtin_bit_cast(f32x4, hi), stage[wave][lane][pp * 4 + 1] = __builtin_bit_cast(f32x4, lo);
+        sp8_split8(v[2], v[3], hi, lo);
+        stage[wave][lane][pp * 4 + 2] = __builtin_bit_cast(f32x4, hi), stage[wave][lane][pp * 4 + 3] = __builtin_bit_cast(f32x4, lo);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stage[wave][lane][pp * 4 + k] = v[k];
+      }
+    }
+    // (one wave reads only what it wrote itself: LDS operations of a wave complete in order)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int T = i * 8 + (lane >> 3), k = lane & 7;
+      const f32x4 piece = stage[wave][T][k];
+      if (wave_idx0 + T < total) *reinterpret_cast<f32x4*>(out + (wave_idx0 + T) * 64 + half * 32 + k * 4) = piece;
     }
   }
 }
