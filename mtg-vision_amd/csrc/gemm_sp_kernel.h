@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
                 x0 = x0 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
                 x1 = x1 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
               }
-              sp8_split8(x0, x1, ah[i], al[i]);
+              sp8_split8_mix(x0, x1, ah[i], al[i]);  // (same values as sp8_split8, 8 vector instructions fewer per 8 elements)
             } else {
               ah[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + shi);
               al[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + slo);
