@@ -521,7 +521,68 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
             for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
         }
       }
-      if (wave_active && !HI16) {
+      if constexpr (AF32 && KS == 2 && !HI16) {
+        // f32 A rows: both k16 steps' fragments are requested first, and the second step's scale + split (24 vector
+        // instructions per fragment) is issued in the shadow of the first step's MFMAs - an in-order wave otherwise
+        // converts, then multiplies, and the matrix pipe idles through every conversion.  Same products, same order.
+        __builtin_amdgcn_sched_barrier(0);  // the next stage's DMA above stays ahead of this stage's arithmetic
+        if (wave_active) {
+          const char* const sb = ring + buf * STG;
+          sp_f4 xa[2][TM][2];
+          sp_h8 bh[2][TN], bl[2][TN];
+  #pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const unsigned shi = (unsigned)(((ks * 4 + h * 2 + 0) ^ swr) << 4);
+            const unsigned slo = (unsigned)(((ks * 4 + h * 2 + 1) ^ swr) << 4);
+  #pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              xa[ks][i][0] = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + shi);
+              xa[ks][i][1] = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + slo);
+              if constexpr (AMODE == 3) {
+                xa[ks][i][0] = xa[ks][i][0] * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
+                xa[ks][i][1] = xa[ks][i][1] * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
+              }
+            }
+  #pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              bh[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + shi);
+              bl[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
+            }
+          }
+          sp_h8 ah[2][TM], al[2][TM];
+  #pragma unroll
+          for (int i = 0; i < TM; ++i) sp8_split8_mix(xa[0][i][0], xa[0][i][1], ah[0][i], al[0][i]);
+  #pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 0) {
+  #pragma unroll
+              for (int i = 0; i < TM; ++i) sp8_split8_mix(xa[1][i][0], xa[1][i][1], ah[1][i], al[1][i]);
+            }
+  #pragma unroll
+            for (int j = 0; j < TN; ++j)
+  #pragma unroll
+              for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
+  #pragma unroll
+            for (int j = 0; j < TN; ++j)
+  #pragma unroll
+              for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][j], al[ks][i], acc[i][j], 0, 0, 0);
+  #pragma unroll
+            for (int j = 0; j < TN; ++j)
+  #pragma unroll
+              for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
+          }
+          // issue order: every LDS read, the first step's conversion, then the first step's MFMAs one by one, each
+          // followed by a share of the second step's conversion
+          constexpr int CV = (AMODE == 3 ? 8 : 0) + 16;  // vector instructions per fragment: scale, split
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM * (AMODE == 3 ? 4 : 2) + 2 * TN), 0);  // DS read
+          __builtin_amdgcn_sched_group_barrier(0x002, CV * TM, 0);                                     // VALU
+  #pragma unroll
+          for (int q = 0; q < 3 * TM * TN; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, (CV * TM + 3 * TM * TN - 1) / (3 * TM * TN), 0);  // VALU
+          }
+        }
+      } else if (wave_active && !HI16) {
         const char* const sb = ring + buf * STG;
   #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
