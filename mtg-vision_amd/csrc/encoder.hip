@@ -495,8 +495,15 @@ void Encoder::body(int n, float* z_out, hipStream_t s) {
     g.KH = 4, g.KW = 1, g.stride = 4, g.stride_w = 1, g.pad = 0;
     g.OH = sh_[0], g.OW = sw_[0], g.OH2 = sh_[0], g.OW2 = sw_[0];
     g.ldo = d[0];
-    gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
-    ln_rows_launch(alt, d[0], 0, cur, d[0], 0, stem_ln_w_, stem_ln_b_, g.M, d[0], 1e-6f, s);
+    const GemmPlan pl = gemm_plan(g.M, g.N, g.K);
+    if (gemm_ln_fusable(g, pl)) {  // the stem's LayerNorm in the conv's epilogue: its output is written once
+      g.Out = cur;
+      g.ln_w = stem_ln_w_, g.ln_b = stem_ln_b_, g.ln_eps = 1e-6f;
+      gemm_launch(g, pl, s);
+    } else {
+      gemm_launch(g, pl, s);
+      ln_rows_launch(alt, d[0], 0, cur, d[0], 0, stem_ln_w_, stem_ln_b_, g.M, d[0], 1e-6f, s);
+    }
   }
 
   for (int st = 0; st < 4; ++st) {

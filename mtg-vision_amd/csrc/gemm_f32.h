@@ -71,6 +71,11 @@ struct GemmArgs {
   float* cand_s = nullptr;
   int* cand_i = nullptr;
   int topk = 0;
+  // LayerNorm over the N outputs of every row fused into the epilogue (the encoder's stem: conv k4 s4 + LN,
+  // convnextv2.py:253-256).  Only where gemm_ln_fusable() says so: one tile covers the whole row, whole tiles only.
+  const float* ln_w = nullptr;
+  const float* ln_b = nullptr;
+  float ln_eps = 0.f;
 };
 
 struct GemmPlan {
@@ -86,6 +91,8 @@ GemmPlan gemm_plan(int M, int N, int K, bool heavy_epilogue = false, bool scaled
 int gemm_grn_segmax(const GemmPlan& p, int hw);
 size_t gemm_grn_part_floats(const GemmPlan& p, int N, int hw);
 void gemm_launch(const GemmArgs& a, const GemmPlan& p, hipStream_t s);
+// can this launch (no activation, no residual, not routed to the LDS-DMA kernel) normalise its rows in the epilogue?
+bool gemm_ln_fusable(const GemmArgs& a, const GemmPlan& p);
 
 // Operand precision of every GEMM launch of the process (see gemm_f32.hip): GEMM_PREC_F32 = f32 MFMA,
 // GEMM_PREC_F16X3 = fp16 hi+lo split, three fp16 MFMAs per product.  Initial value from MTGV_GEMM_PREC=f32|f16x3.

@@ -318,7 +318,24 @@ size_t gemm_grn_part_floats_max(int M, int N, int hw) {
   return mx;
 }
 
+bool gemm_ln_fusable(const GemmArgs& a, const GemmPlan& pl) {
+  static const bool on = [] { const char* e = getenv("MTGV_GEMM_LN"); return e == nullptr || atoi(e) != 0; }();
+  if (!on) return false;
+  const bool conv = !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.stride_w <= 1 && a.pad == 0);
+  const bool remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
+  // the instance that carries the epilogue: conv gather, 128 x 96 x 16 tile; one tile per row, whole tiles, plain f32 rows out
+  if (!(pl.tm == 1 && pl.tn == 3 && pl.bk == 16 && conv && a.N == pl.bn() && a.M % pl.bm() == 0)) return false;
+  if (a.batch != 1 || a.act != ACT_NONE || a.res != nullptr || a.a_scale != nullptr || a.grn_part != nullptr || a.topk > 0 ||
+      a.crop_boxes != nullptr || a.m_count != nullptr || remap || a.out_fmt != 0 || a.a_fmt != 0)
+    return false;
+  GemmArgs t = a;
+  t.ln_w = nullptr;
+  return gemm_sp_plan(t).cfg < 0;  // (the LDS-DMA kernel has no such epilogue)
+}
+
 void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
+  if (a.ln_w != nullptr)
+    MTGV_CHECK(a.ln_b != nullptr && gemm_ln_fusable(a, pl), ERR_INVALID, "gemm: this launch cannot normalise its rows in the epilogue");
   MTGV_CHECK(a.batch >= 1 && a.batch <= 65535, ERR_INVALID, "gemm: batch=%d", a.batch);
   MTGV_CHECK(a.M > 0 && a.N > 0 && a.K > 0, ERR_INVALID, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   MTGV_CHECK(a.K % 4 == 0 && a.Cin % 4 == 0 && a.c_total % 4 == 0 && a.c_off % 4 == 0, ERR_INVALID,

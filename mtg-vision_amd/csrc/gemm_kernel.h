@@ -476,6 +476,41 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? (BK == 16 ? 6 : 4) : TM * TN =
             }
           }
         }
+    } else if constexpr (EPI == 2) {
+      // LayerNorm over the row (the tile holds all N = BN columns of its rows: gemm_ln_fusable): a row's values sit in
+      // the 32 lanes of one half-wave x TN column blocks; sums over the blocks in j order, then a butterfly over the
+      // lanes (the same two-pass form as ln_rows_kernel: mean, then the squared deviations).
+      float lw[TN], lb[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) lw[j] = p.ln_w[j * 32 + col], lb[j] = p.ln_b[j * 32 + col];
+      const float inv_n = 1.0f / (float)BN;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long rr = i * 32 + (r & 3) + 8 * (r >> 2);
+          float v[TN];
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            v[j] = PREC == 1 ? __builtin_fmaf(acc[i][j][r], wsv[j], bv[j]) : acc[i][j][r] + bv[j];
+            sum += v[j];
+          }
+#pragma unroll
+          for (int m = 16; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+          const float mean = sum * inv_n;
+          float sq = 0.f;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            v[j] -= mean;
+            sq += v[j] * v[j];
+          }
+#pragma unroll
+          for (int m = 16; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+          const float rstd = 1.0f / sqrtf(sq * inv_n + p.ln_eps);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) (obase + rr * p.ldo + j * 32)[loff] = v[j] * rstd * lw[j] + lb[j];
+        }
     } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -612,6 +647,11 @@ template <int PREC>
 static bool gemm_dispatch(const GemmDev& g, const GemmPlan& pl, bool conv, bool apro, int grid, hipStream_t s) {
   if (g.a.topk > 0) {
     launch_one<1, 2, 16, false, false, 1, ACT_NONE, PREC>(g, grid, s);
+    return true;
+  }
+  if (g.a.ln_w != nullptr) {  // fused LayerNorm epilogue: the stem's tile only (gemm_ln_fusable)
+    if (!(pl.tm == 1 && pl.tn == 3 && pl.bk == 16 && conv && !apro && g.a.act == ACT_NONE)) return false;
+    launch_one<1, 3, 16, true, false, 2, ACT_NONE, PREC>(g, grid, s);
     return true;
   }
 #define MTGV_CASE(TM_, TN_, BK_)                                \

@@ -224,7 +224,7 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
   if (!sp_enabled() || gemm_precision() != GEMM_PREC_F16X3) return none();
   const bool conv = is_conv(a);
   const bool remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
-  if (a.batch != 1 || a.crop_boxes != nullptr || a.m_count != nullptr) return none();
+  if (a.batch != 1 || a.crop_boxes != nullptr || a.m_count != nullptr || a.ln_w != nullptr) return none();
   if (a.topk > 0) {  // match path: 128 x 192 tiles, f32 queries by DMA (A mode 4), fused top-k (gemm_sp_kernel.h, EPI 16)
     if (sp8_in || conv || a.K % 8 != 0 || a.c_total % 8 != 0 || a.c_off % 8 != 0 || ((uintptr_t)a.A & 15) != 0 || a.a_scale != nullptr ||
         a.a_mul != 1.0f || a.res != nullptr || a.act != ACT_NONE || a.M < 128 || a.N < 192 || !sp8_lookup(a.W, a.K, nullptr, nullptr) ||
