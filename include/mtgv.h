@@ -62,14 +62,6 @@ MTGV_API int mtgv_device_count(void);
 #define MTGV_PREC_F32 0
 #define MTGV_PREC_F16X3 1
 MTGV_API int mtgv_set_gemm_precision(int32_t prec);
-/* The one kernel of the library that exists in a packed-FP32 build as well (depthwise 7x7 + LayerNorm, VALU-bound on its
- * stencil: v_pk_fma_f32 halves the instruction count, results bit-identical) is subject to the same contract from the
- * other side: it is launched only while the process states that the library's launches are not concurrent with F16X3
- * launches of another stream or process on the same GPU.  Initial value: 0 unless MTGV_PACKED_FP32=1 (measured on MI355X
- * the packed build is 19 % slower than the plain one, profiles/README.md: it is kept for re-measurement, not used by
- * default).  Not thread-safe: set it while no library call is in flight. */
-MTGV_API int mtgv_set_packed_fp32(int32_t allow);
-MTGV_API int mtgv_get_packed_fp32(void);
 MTGV_API int mtgv_get_gemm_precision(int32_t* prec);
 
 /* Measurement aid: when enabled, every launch of the GEMM kernel is bracketed by HIP

@@ -69,11 +69,7 @@ def build(force: bool = False, jobs: int = 6, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        flags = list(FLAGS)
-        if src.endswith("_pk.hip"):  # the one translation unit built WITH packed-FP32 instructions (rowops_pk.hip)
-            i = flags.index("-packed-fp32-ops")
-            del flags[i - 3 : i + 1]
-        cmd = [HIPCC, *flags, "-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

@@ -106,11 +106,6 @@ MTGV_API int mtgv_get_gemm_precision(int32_t* prec) {
   });
 }
 
-MTGV_API int mtgv_set_packed_fp32(int32_t allow) {
-  return guarded([&] { set_packed_fp32(allow); });
-}
-MTGV_API int mtgv_get_packed_fp32(void) { return packed_fp32_allowed() ? 1 : 0; }
-
 // ---- GEMM launch profiler ----
 MTGV_API int mtgv_profile_gemm(int32_t enable) {
   return guarded([&] { gemm_profile_enable(enable != 0); });

@@ -1,6 +1,5 @@
-// Depthwise 7x7 + LayerNorm kernel body, shared by two translation units: rowops.hip (built like the rest of the library,
-// without packed-FP32 VALU instructions) and rowops_pk.hip (packed FP32 allowed: v_pk_fma_f32 does two of the stencil's
-// FMAs per instruction).  PK only keeps the two instantiations apart at link time.
+// Depthwise 7x7 + LayerNorm kernel bodies (instantiated in rowops.hip, built like the rest of the library without
+// packed-FP32 VALU instructions; PK is always 0 - it kept a packed build of round 3 apart at link time).
 #pragma once
 #include "common.h"
 #include "sp8.h"
@@ -286,7 +285,8 @@ static void dwconv7_ln_launch_t(const float* in, const float* w49, const float* 
   // single-row kernel): 4-pixel strips x 3 rows with the tap table in LDS while table + partial sums fit the default
   // 64 KB window (C <= 192: 121.5 vs 144-155 us at 256 x 48 x 32 x 96, 60.9 vs 66.7 at 24 x 16 x 192), else 3 rows of the
   // widest strip (34.7 vs 38.6 us at 12 x 8 x 384, 20.3 vs 24.7 at 6 x 4 x 768).  MTGV_DW_ROWS=0: single-row kernel.
-  static const bool rows_on = !(getenv("MTGV_DW_ROWS") && atoi(getenv("MTGV_DW_ROWS")) == 0);
+  const char* const rows_env = getenv("MTGV_DW_ROWS");  // read per call: tests compare the forms inside one process
+  const bool rows_on = !(rows_env && atoi(rows_env) == 0);
   if constexpr (PK == 0)  // the rows kernel is not keyed by PK: only the TU built without packed FP32 may instantiate it
   if (rows_on && W >= 4) {
     const int c4n_ = C / 4, S_ = 256 / c4n_;

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ q
   publish();
   // Any row not scored yet has an approximate score <= max(a_R, s_cut), hence an exact score <= that + EPS.
   const float bound = fmaxf(s_aR, s_cut);
-  if (bound > -INFINITY && !(s_kth >= bound + PRE_EPS)) {
+  if (bound > -INFINITY && !(s_kth > bound + PRE_EPS)) {
     // The bound does not prove the answer (near-duplicate rows, or two strong rows inside one wave range): score exactly
     // every row that could still enter - reported candidates whose own approximate score comes within EPS of the k-th
     // best, and all columns of the ranges whose cut-off does.  Each is scored once: the lists cannot hold duplicates.
@@ -222,13 +222,13 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ q
     __syncthreads();
     for (int p = wave; p < ncand; p += 4) {
       const int i = ci[p];
-      if (i < 0 || !(cs[p] > need)) continue;
+      if (i < 0 || !(cs[p] >= need)) continue;
       bool taken = false;
       for (int t = 0; t < PRE_R; ++t) taken |= sel_p[t] == p;
       if (!taken) topk_insert(bs, bi, k, exact_dot_wave(q, bank + (long)i * K, K, lane), (long)i);
     }
     for (int w = 0; w < slots; ++w) {  // every wave walks the ranges; a dangerous range's columns are dealt out 16 at a time
-      if (!(cs[w * PRE_KP + PRE_KP - 1] > need)) continue;
+      if (!(cs[w * PRE_KP + PRE_KP - 1] >= need)) continue;
       const long c0 = (long)w * range_cols;
       for (long cb = c0 + wave * 4; cb < c0 + range_cols; cb += 16) {
         long c = cb + (lane >> 4);

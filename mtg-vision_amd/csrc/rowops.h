@@ -19,14 +19,6 @@ bool dwconv7_ln_supported(int W, int C);
 void dwconv7_ln_launch(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b, float* out,
                        int N, int H, int W, int C, float eps, hipStream_t s, int out_fmt = 0);
 
-void dwconv7_ln_launch_pk(const float* in, const float* w49, const float* bias, const float* ln_w, const float* ln_b, float* out,
-                          int N, int H, int W, int C, float eps, hipStream_t s, int out_fmt);  // rowops_pk.hip
-// May kernels built with packed-FP32 VALU instructions be launched?  They have been seen to lose lanes when a
-// split-precision GEMM of ANOTHER stream (or process) shares the GPU with them, and the one kernel
-// built that way measured slower than its plain build: off unless MTGV_PACKED_FP32=1 or mtgv_set_packed_fp32(1).
-bool packed_fp32_allowed();
-void set_packed_fp32(int allow);
-
 // (N,C,H,W) f32 -> (N,H,W,Cp) f32, y = x*scale + shift, channels C..Cp-1 zero.  (x*2-1: convnextv2ae.py:257-258)
 void nchw_to_nhwc_launch(const float* in, float* out, int N, int C, int H, int W, int Cp, float scale, float shift,
                          hipStream_t s);

@@ -61,9 +61,12 @@ __device__ __forceinline__ void sp8_split8(const sp_f4 x0, const sp_f4 x1, sp_h8
 // __builtin_amdgcn_global_load_lds once its loop passes have folded the base into a per-lane 64-bit pointer; with it a
 // stage's pieces cost no vector arithmetic (the stage advance is two scalar adds) and the instruction carries half the
 // address bytes.  The compiler does not see the instruction: callers order it by their own s_waitcnt vmcnt(N).
+// Two things hipcc does for its own builtin and the assembler does not do inside inline asm: the wait state gfx950
+// needs between an SALU write of M0 and the LDS-DMA that reads it (s_nop 0), and making the LDS address wave-uniform
+// (readfirstlane here, so that the "s" constraint never receives a value the compiler only believes to be uniform).
 __device__ __forceinline__ void sp_dma16_saddr(const char* base, uint32_t off, const char* lds) {
-  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)lds;
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+  const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)lds);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
 
 // A thread that holds 4 consecutive channels (channel quad c4 of a pixel) turns them into its half of an SP8 chunk

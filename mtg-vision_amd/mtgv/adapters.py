@@ -118,6 +118,17 @@ def _mask_segments(mask: np.ndarray, strategy: str = "all") -> np.ndarray:
     return p[:, ::-1] - 1.0  # (x, y), undo the padding
 
 
+def _outline_from_extents(ext: np.ndarray) -> np.ndarray:
+    """The "outline" form of `InstanceSeg.points`: `ext` (rows, 2) holds the leftmost and rightmost mask pixel of every
+    image row (-1 where the row is empty, as quads.hip reports them); returns the polygon left edge top to bottom, then
+    right edge bottom to top, (x, y).  Notches that open to the left or right survive, notches that open up or down
+    are filled (every row keeps only its extremes)."""
+    rows = np.nonzero(ext[:, 0] >= 0)[0]
+    left_edge = np.stack([ext[rows, 0], rows], 1)
+    right_edge = np.stack([ext[rows[::-1], 1], rows[::-1]], 1)
+    return np.concatenate([left_edge, right_edge])
+
+
 def _largest_contour(mask: np.ndarray) -> np.ndarray:
     """Every boundary pixel (x, y) of the largest 8-connected blob of a binary mask, in trace order (test helper and
     the dense form of `_mask_segments(mask, "largest")`)."""
@@ -297,16 +308,20 @@ class CardSegmenter:
     models are not loadable without the package (and are never unpickled here)."""
 
     def __init__(self, model_path: str | Path = None, *, state_dict=None, detector: Optional[Detector] = None, max_batch: int = 1,
-                 contours="outline"):
+                 contours="trace"):
         """contours: what `InstanceSeg.points` holds (the reference: ultralytics `masks.xy`, od_export.py:152-153).
-        "outline" (default; True is accepted for it): the mask's outline as the GPU's row extents - left edge top to
-        bottom, right edge bottom to top, at most 2 x 640 points - with the oriented quad fitted on the GPU
-        (quads.hip); one device-to-host copy of those integers per call, no mask leaves the device.
-        "trace": every 640 x 640 mask is copied to the host and its blobs are traced there like
-        cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) (`_mask_segments`; scipy), the quad fitted lazily on the host.
+        "trace" (default; True is accepted for it): the reference-shaped points - every 640 x 640 mask is copied to the
+        host and its blobs are traced there like cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) (`_mask_segments`;
+        scipy), notches of the reference's U-shaped card masks (od_export.py:57-60) included; the quad and the closed
+        polygon are derived lazily on the host as `InstanceSeg._orient` does.
+        "outline": the opt-in fast path - the mask's outline as the GPU's row extents (left edge top to bottom, right edge
+        bottom to top, at most 2 x 640 points) with the oriented quad fitted on the GPU (quads.hip); one device-to-host
+        copy of those integers per call, no mask leaves the device.  A row-extent outline FILLS any notch that opens
+        upwards or downwards, so `points` / `points_closed` differ from the reference for upright and upside-down cards
+        (tests/test_adapters_cpu.py pins what they hold); quads, direction vectors and crops do not.
         False: only the four GPU-fitted corners per card (they double as `points`) - for tracking loops."""
         if contours is True:
-            contours = "outline"
+            contours = "trace"
         assert contours in ("outline", "trace", False), contours
         self.contours = contours
         if detector is not None:
@@ -350,10 +365,7 @@ class CardSegmenter:
             if not good:
                 continue
             if want_ext:
-                rows = np.nonzero(ext[i, :, 0] >= 0)[0]
-                left_edge = np.stack([ext[i, rows, 0], rows], 1)            # top to bottom
-                right_edge = np.stack([ext[i, rows[::-1], 1], rows[::-1]], 1)  # bottom to top
-                pts = to_frame(np.concatenate([left_edge, right_edge])).astype(np.float32)
+                pts = to_frame(_outline_from_extents(ext[i])).astype(np.float32)
             else:
                 pts = q.astype(np.float32)
             seg = InstanceSeg(points=pts, label=0, conf=np.asarray(conf).tolist())

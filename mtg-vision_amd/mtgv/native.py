@@ -54,8 +54,6 @@ SIGNATURES = {
     "mtgv_device_count": (C.c_int, []),
     "mtgv_set_gemm_precision": (C.c_int, [c_i32]),
     "mtgv_get_gemm_precision": (C.c_int, [C.POINTER(c_i32)]),
-    "mtgv_set_packed_fp32": (C.c_int, [c_i32]),
-    "mtgv_get_packed_fp32": (C.c_int, []),
     "mtgv_profile_gemm": (C.c_int, [c_i32]),
     "mtgv_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64)]),
     "mtgv_profile_gemm_bytes": (C.c_int, [C.POINTER(C.c_double)]),
@@ -169,16 +167,6 @@ def set_gemm_precision(name: str) -> None:
     if name not in PRECISIONS:
         raise AssertionError(f"precision {name!r}: expected one of {sorted(PRECISIONS)}")
     check(lib().mtgv_set_gemm_precision(PRECISIONS[name]))
-
-
-def set_packed_fp32(allow: bool) -> None:
-    """Allow / forbid the packed-FP32 build of dwconv7_ln (include/mtgv.h: only while no other stream or process runs
-    f16x3 launches on the same GPU)."""
-    check(lib().mtgv_set_packed_fp32(1 if allow else 0))
-
-
-def get_packed_fp32() -> bool:
-    return bool(lib().mtgv_get_packed_fp32())
 
 
 def get_gemm_precision() -> str:

@@ -90,7 +90,6 @@ class Pipeline:
         section 5 - and tests/test_gpu_overlap.py guards the combination.)"""
         if not self.overlap_enabled():
             return [self.run(frames, flip_rgb) for frames in batches]
-        native.set_packed_fp32(False)  # two streams from here on: no packed-FP32 kernel beside the f16x3 GEMMs (mtgv.h; off by default)
         dev = self.detector.device
         if not hasattr(self, "_s_det"):
             self._s_det, self._s_enc = torch.cuda.Stream(dev), torch.cuda.Stream(dev)

@@ -198,8 +198,8 @@ def _card_frame_mask(quad, size=640):
     return m
 
 
-def test_card_segmenter_default_outline_from_the_device(monkeypatch):
-    """default path (contours="outline"): points = the mask's row-extent outline computed on the GPU, quad fitted on the
+def test_card_segmenter_outline_from_the_device(monkeypatch):
+    """opt-in fast path (contours="outline"): points = the mask's row-extent outline computed on the GPU, quad fitted on the
     GPU; against the host path that copies the masks and traces them (contours="trace") on card-shaped masks: same cards,
     corners within 1.5 px, and the outline is a polygon of at most 2 x 640 points that covers the mask."""
     import mtgv.adapters as A
@@ -218,8 +218,9 @@ def test_card_segmenter_default_outline_from_the_device(monkeypatch):
     fake = Detections(boxes, torch.tensor([0.9, 0.8], device="cuda"), torch.zeros(2, dtype=torch.int64, device="cuda"),
                       torch.zeros(2, dtype=torch.int64, device="cuda"), logits)
     monkeypatch.setattr(det, "detect", lambda *a, **k: fake)
-    seg_dev = A.CardSegmenter(detector=det)(frame)
-    seg_host = A.CardSegmenter(detector=det, contours="trace")(frame)
+    seg_dev = A.CardSegmenter(detector=det, contours="outline")(frame)
+    seg_host = A.CardSegmenter(detector=det)(frame)  # the default: reference-shaped traced points
+    assert A.CardSegmenter(detector=det).contours == "trace"
     assert len(seg_dev) == len(seg_host) == 2
     for d, h, q in zip(seg_dev, seg_host, quads):
         assert d.points.ndim == 2 and d.points.shape[1] == 2 and 8 < d.points.shape[0] <= 2 * 640

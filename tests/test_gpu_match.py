@@ -216,6 +216,40 @@ def test_two_pass_match_falls_back_on_clustered_banks():
     assert (ia[rows] == ib[rows]).all()
 
 
+def test_two_pass_exact_duplicates_inside_one_range_tie_by_id():
+    """exact duplicates of the best row inside ONE 96-column wave range, more of them than the range reports (PRE_KP = 2):
+    the unreported duplicate with the lowest id has an exact score EQUAL to the k-th best, so only the inclusive forms of
+    the proof / re-scoring comparisons (match.hip rerank_kernel) return it - as the one-pass path does (score desc, id asc)"""
+    from mtgv.matcher import Matcher
+
+    g = torch.Generator(device="cuda").manual_seed(6)
+    bank = torch.randn((8192, 768), generator=g, device="cuda")
+    q = torch.randn((128, 768), generator=g, device="cuda")
+    for qi, rows in ((3, [960 + 5, 960 + 17, 960 + 40, 960 + 95]), (77, [4800 + 90, 4800 + 2, 4800 + 50])):  # 960 = 10 * 96, 4800 = 50 * 96
+        bank[rows] = q[qi]
+    m = Matcher(768, capacity=8192)
+    m.add(bank)
+    for k in (1, 2, 3):
+        (ia, sa), (ib, sb) = _both_paths(m, q, k)
+        assert ia[3].tolist() == [965, 977, 1000][:k] and ia[77].tolist() == [4802, 4850, 4890][:k]
+        assert (ia == ib).all()
+        assert (sa - sb).abs().max().item() < 2e-6
+
+
+def test_small_bank_single_query():
+    """one query against a 300-row, 768-d bank with k = 3 (tools/debug/launch_fail_probe.py, the round-3 reproducer of a
+    failing launch) - the convert-on-load top-k path with a single 128-row tile of which one row is valid"""
+    from mtgv.matcher import Matcher
+
+    rng = np.random.default_rng(5)
+    bank = rng.standard_normal((300, 768)).astype(np.float32)
+    m = Matcher(768, capacity=512)
+    m.add(bank)
+    q = np.ones((1, 768), np.float32)
+    ids, sc = m.match(q[0], 3)
+    _check(ids, sc, q, bank, 3)
+
+
 def test_score_threshold_small_batch():
     from mtgv.matcher import Matcher, merge_topk
 

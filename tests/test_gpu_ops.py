@@ -150,27 +150,31 @@ def test_block_vs_oracle(n, h, w, c, act):
 
 
 @pytest.mark.parametrize("n,h,w,c", [(3, 48, 32, 96), (2, 12, 8, 384), (2, 28, 28, 192), (2, 7, 7, 768), (1, 14, 14, 384), (1, 5, 9, 80), (2, 6, 4, 768)])
-def test_packed_fp32_build_of_dwconv_ln_is_bit_identical(n, h, w, c):
-    """the packed-FP32 build of dwconv7_ln (the single-row kernel) and the plain build (the row-group kernels: three output
-    rows per thread, ragged last rows and strips included) give the same bits (whole block)"""
+def test_dwconv_ln_forms_are_bit_identical(n, h, w, c):
+    """the single-row form of dwconv7_ln (MTGV_DW_ROWS=0) and the row-group forms (three output rows per thread, ragged
+    last rows and strips included) give the same bits (whole block)"""
+    import os
+
     nv = _lib()
     rng = np.random.default_rng(c)
     f = lambda *sh: _dev(rng.standard_normal(sh).astype(np.float32) * 0.3)  # noqa: E731
     X = f(n, h, w, c)
     args = [f(49, c), f(c), 1 + f(c), f(c), f(4 * c, c), f(4 * c), f(1, 1, 1, 4 * c), f(1, 1, 1, 4 * c), f(c, 4 * c), f(c)]
     ws = torch.empty(int(nv.lib().mtgv_op_block_workspace_floats(n, h, w, c)), device="cuda")
-    before = nv.get_packed_fp32()
+    before = os.environ.get("MTGV_DW_ROWS")
     outs = []
     try:
-        for allow in (True, False):
-            nv.set_packed_fp32(allow)
-            assert nv.get_packed_fp32() == allow
+        for rows in ("0", "1"):
+            os.environ["MTGV_DW_ROWS"] = rows  # read per launch (dwconv7_ln_kernel.h)
             out = torch.full((n, h, w, c), float("nan"), device="cuda")
             nv.check(nv.lib().mtgv_op_block(nv.ptr(X), nv.ptr(out), n, h, w, c, 2, *[nv.ptr(a) for a in args], nv.ptr(ws), nv.stream()))
             torch.cuda.synchronize()
             outs.append(out)
     finally:
-        nv.set_packed_fp32(before)
+        if before is None:
+            os.environ.pop("MTGV_DW_ROWS", None)
+        else:
+            os.environ["MTGV_DW_ROWS"] = before
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 

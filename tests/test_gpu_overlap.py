@@ -3,9 +3,8 @@
 Regression guard for a hardware-level interaction measured on MI355X: with packed-FP32 VALU instructions in the
 library, a ConvNeXt block running beside the split-precision (f16x3) GEMMs of the detector on a second stream came out
 wrong in 5-50 % of the runs (one 16-lane group of the fused dwconv7+LayerNorm kernel lost a packed result).  The
-library is compiled without those instructions (mtg-vision_amd/build.py), except for the one-stream build of dwconv7_ln,
-which a caller with several streams switches off (mtgv_set_packed_fp32(0), as this test and Pipeline.run_many do); this
-test repeats the reproducer under that contract.
+library is compiled without those instructions (mtg-vision_amd/build.py: every translation unit since round 4); this
+test repeats the reproducer.
 """
 import os
 
@@ -19,10 +18,8 @@ pytestmark = pytest.mark.gpu
 def _env_guard():
     from mtgv import native
 
-    before, tile, packed = native.get_gemm_precision(), os.environ.get("MTGV_GEMM_TILE"), native.get_packed_fp32()
-    native.set_packed_fp32(False)  # two streams below: the contract of include/mtgv.h
+    before, tile = native.get_gemm_precision(), os.environ.get("MTGV_GEMM_TILE")
     yield native
-    native.set_packed_fp32(packed)
     native.set_gemm_precision(before)
     if tile is None:
         os.environ.pop("MTGV_GEMM_TILE", None)
