@@ -75,6 +75,15 @@ class Detector {
   void conv0(const uint8_t* frames, int n, int flip, hipStream_t s);
   void sppf(const std::string& prefix, const View& in, const View& spp, const View& out, int n, hipStream_t s);
   void proto(const std::string& head, const View& p3, int n, hipStream_t s);
+  void head_level_v8(int l, int n, hipStream_t s);
+  void head_level_v11(int l, int n, hipStream_t s);
+  // Fork-join inside one forward (library-owned streams and events, library kernels only - the concurrency contract
+  // of include/mtgv.h): the prototype branch and the P3 / P4 head branches leave the caller's stream as soon as their
+  // input exists and rejoin it before decode / the mask product.  fork_after(s, i): side stream i starts after
+  // everything enqueued on s so far; join_into(s, i): s continues after everything enqueued on side stream i so far.
+  bool fork_enabled() const;
+  hipStream_t fork_after(hipStream_t s, int i);
+  void join_into(hipStream_t s, int i);
   bool v11() const { return cfg_.arch == 11; }
   View take(int n, int h, int w, int c);
   View view(const std::string& k) const;
@@ -98,6 +107,7 @@ class Detector {
   std::string head_ = "model.22";
   ConvW head_first_[3], head_box2_[3], head_cls2_[3], head_coef2_[3], head_box3_[3], head_cls3_[3], head_coef3_[3];
   ConvW proto_up_[4];
+  ConvW proto_up_all_;  // the four phase matrices stacked (kh, kw, cout): the ConvTranspose as one launch (GemmArgs::os_nq)
 
   // activations (arena)
   DevBuf arena_;
@@ -108,6 +118,10 @@ class Detector {
   size_t nms_ws_bytes_ = 0;
   int last_n_ = 0;
   int fmt_ = 0;  // activation format of the forward in progress (0 f32, 1 SP8)
+  static constexpr int NSIDE = 3;  // 0: prototype branch, 1: P3 head, 2: P4 head
+  hipStream_t side_[NSIDE] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork_[NSIDE] = {nullptr, nullptr, nullptr}, ev_join_[NSIDE] = {nullptr, nullptr, nullptr};
+  bool side_busy_[NSIDE] = {false, false, false};  // forked in the forward in progress and not joined yet
 };
 
 }  // namespace mtgv

@@ -386,6 +386,36 @@ Detector::~Detector() {
     (void)hipFree(p);
   }
   if (nms_ws_) (void)hipFree(nms_ws_);
+  for (int i = 0; i < NSIDE; ++i) {
+    if (side_[i]) (void)hipStreamDestroy(side_[i]);
+    if (ev_fork_[i]) (void)hipEventDestroy(ev_fork_[i]);
+    if (ev_join_[i]) (void)hipEventDestroy(ev_join_[i]);
+  }
+}
+
+bool Detector::fork_enabled() const {
+  const char* e = getenv("MTGV_DET_FORK");  // read per call: tests and tools compare both schedules in one process
+  return !count_flops_ && (e == nullptr || atoi(e) != 0);
+}
+
+hipStream_t Detector::fork_after(hipStream_t s, int i) {
+  if (!fork_enabled()) return s;
+  if (side_[i] == nullptr) {
+    HIP_OK(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&ev_fork_[i], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
+  }
+  HIP_OK(hipEventRecord(ev_fork_[i], s));
+  HIP_OK(hipStreamWaitEvent(side_[i], ev_fork_[i], 0));
+  side_busy_[i] = true;
+  return side_[i];
+}
+
+void Detector::join_into(hipStream_t s, int i) {
+  if (!side_busy_[i]) return;
+  HIP_OK(hipEventRecord(ev_join_[i], side_[i]));
+  HIP_OK(hipStreamWaitEvent(s, ev_join_[i], 0));
+  side_busy_[i] = false;
 }
 
 void Detector::set_param(const char* key, const float* host, int64_t numel) {
@@ -557,6 +587,15 @@ void Detector::finalize() {
         c.w = upload(m, ci), c.b = bias, c.cout = co, c.cin = ci, c.k = 1;
         proto_up_[kh * 2 + kw] = c;
       }
+    // all four phases as one [4 co][ci] operand, rows (kh, kw, o): one launch reads the input once (proto())
+    std::vector<float> m4((size_t)4 * co * ci), b4((size_t)4 * co);
+    const auto& bsrc = raw_.at(H + ".proto.upsample.bias").data;
+    for (int q = 0; q < 4; ++q)
+      for (int o = 0; o < co; ++o) {
+        b4[(size_t)q * co + o] = bsrc[o];
+        for (int i = 0; i < ci; ++i) m4[((size_t)q * co + o) * ci + i] = w.data[(((size_t)i * co + o) * 2 + (q >> 1)) * 2 + (q & 1)];
+      }
+    proto_up_all_.w = upload(m4, ci), proto_up_all_.b = upload(b4), proto_up_all_.cout = 4 * co, proto_up_all_.cin = ci, proto_up_all_.k = 1;
   }
 
   if (v11()) {
@@ -585,7 +624,7 @@ void Detector::finalize() {
   sz(s8, s8, 3 * c64 / 2), sz(s8, s8, c64 / 2), sz(s8, s8, c64);        // 15, p3
   sz(s16, s16, 3 * c128 / 2), sz(s16, s16, c128 / 2), sz(s16, s16, c128);  // 18, p4
   sz(s32, s32, 3 * c256 / 2), sz(s32, s32, c256 / 2), sz(s32, s32, c256);  // 21, p5
-  sz(s8, s8, 160), sz(s8, s8, 160);                                     // head t1/t2 (largest level)
+  sz(s8, s8, 160), sz(s8, s8, 160), sz(s16, s16, 160), sz(s16, s16, 160), sz(s32, s32, 160), sz(s32, s32, 160);  // head t1/t2 per level (the levels' branches run concurrently)
   sz(s8, s8, RAW_CT), sz(s16, s16, RAW_CT), sz(s32, s32, RAW_CT);       // rawhead
   sz(s8, s8, npr_), sz(s4, s4, npr_), sz(s4, s4, npr_), sz(s4, s4, nm_);  // proto
   sz(1, na_, 4 + cfg_.nc + nm_);                                        // pred
@@ -612,7 +651,9 @@ void Detector::finalize() {
   v_["cat15"] = take(nb, s8, s8, 3 * c64 / 2), v_["tmp15"] = take(nb, s8, s8, c64 / 2), v_["p3"] = take(nb, s8, s8, c64);
   v_["cat18"] = take(nb, s16, s16, 3 * c128 / 2), v_["tmp18"] = take(nb, s16, s16, c128 / 2), v_["p4"] = take(nb, s16, s16, c128);
   v_["cat21"] = take(nb, s32, s32, 3 * c256 / 2), v_["tmp21"] = take(nb, s32, s32, c256 / 2), v_["p5"] = take(nb, s32, s32, c256);
-  v_["t1"] = take(nb, s8, s8, 160), v_["t2"] = take(nb, s8, s8, 160);
+  v_["t1_0"] = take(nb, s8, s8, 160), v_["t2_0"] = take(nb, s8, s8, 160);
+  v_["t1_1"] = take(nb, s16, s16, 160), v_["t2_1"] = take(nb, s16, s16, 160);
+  v_["t1_2"] = take(nb, s32, s32, 160), v_["t2_2"] = take(nb, s32, s32, 160);
   rawhead_[0] = take(nb, s8, s8, RAW_CT).p, rawhead_[1] = take(nb, s16, s16, RAW_CT).p, rawhead_[2] = take(nb, s32, s32, RAW_CT).p;
   v_["pr1"] = take(nb, s8, s8, npr_), v_["pr2"] = take(nb, s4, s4, npr_), v_["pr3"] = take(nb, s4, s4, npr_);
   v_["protos"] = take(nb, s4, s4, nm_);
@@ -699,7 +740,25 @@ void Detector::proto(const std::string& H, const View& p3, int n, hipStream_t s)
   conv(cw_.at(H + ".proto.cv1"), p3, view("pr1"), 1, ACT_SILU, nullptr, n, s);
   {
     const View in = view("pr1"), out = view("pr2");
-    for (int q = 0; q < 4; ++q) {
+    // SP8 activations (LDS-DMA kernel): one launch with N = 4 * 64 columns whose epilogue scatters column group q to
+    // output phase (q / 2, q % 2) - the input is read once instead of four times (round 3: 4 x 27 us at 3.9 TB/s, bound
+    // by that re-read).  Same products in the same order per output element: bit-identical to the four launches.
+    const char* const up1 = getenv("MTGV_PROTO_UP1");  // read per call (A/B in one process); 0: the four-launch form
+    const bool one_launch = up1 == nullptr || atoi(up1) != 0;
+    const bool single = one_launch && fmt_ == 1 && !count_flops_ && npr_ % 8 == 0;
+    if (single) {
+      const ConvW& w = proto_up_all_;
+      GemmArgs g;
+      g.A = in.p, g.W = w.w, g.bias = w.b, g.Out = out.p;
+      g.M = n * in.H * in.W, g.N = w.cout, g.K = w.cin;
+      g.H = in.H, g.Wd = in.W, g.c_total = in.ct, g.c_off = 0, g.Cin = w.cin;
+      g.OH = in.H, g.OW = in.W;
+      g.os = 2, g.oy = 0, g.ox = 0, g.os_nq = npr_, g.OH2 = out.H, g.OW2 = out.W;
+      g.ldo = out.ct;
+      g.a_fmt = in.fmt, g.out_fmt = out.fmt;
+      gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
+    }
+    for (int q = 0; q < 4 && !single; ++q) {
       const ConvW& w = proto_up_[q];
       GemmArgs g;
       g.A = in.p, g.W = w.w, g.bias = w.b, g.Out = out.p;
@@ -766,6 +825,7 @@ void Detector::head_tail(int n, int* n_det, float* boxes, float* conf, int* cls,
   HIP_OK(hipGetLastError());
   nms_launch(pred_, n, cfg_.nc, nm_, na_, cfg_.conf, cfg_.iou, cfg_.max_det, 7680.0f, n_det, boxes, conf, cls, keep_idx, coef_,
              nms_ws_, nms_ws_bytes_, s);
+  join_into(s, 0);  // the prototype branch ran beside the heads, decode and NMS (one workgroup per frame: 32 of 256 CUs)
   if (mask_logits != nullptr) {
     // masks = coeffs @ protos^T per image, cropped to the box (process_mask / crop_mask)
     const View pr = view("protos");
@@ -854,28 +914,33 @@ void Detector::forward_v8(const uint8_t* frames, int n, int flip, hipStream_t s)
   c2f(12, cat11, n12, n, s);
   if (!count_flops_) upsample2x_launch(n12.p, n12.ct, n12.co, cat14.p, cat14.ct, 0, n, n12.H, n12.W, c128, s);
   c2f(15, cat14, V("p3"), n, s);
+  // P3 exists: the prototype branch (0.5 ms of chip-filling launches) and the P3 head leave the caller's stream; the
+  // rest of the neck - 100..400-tile launches that cannot fill 256 CUs on their own - runs beside them
+  proto(head_, V("p3"), n, fork_after(s, 0));
+  head_level_v8(0, n, fork_after(s, 1));
   conv(cw_.at("model.16"), V("p3"), cat17.slice(0, c64), 2, ACT_SILU, nullptr, n, s);
   c2f(18, cat17, V("p4"), n, s);
+  head_level_v8(1, n, fork_after(s, 2));
   conv(cw_.at("model.19"), V("p4"), cat20.slice(0, c128), 2, ACT_SILU, nullptr, n, s);
   c2f(21, cat20, V("p5"), n, s);
+  head_level_v8(2, n, s);
+  join_into(s, 1), join_into(s, 2);  // (the prototype branch is joined in head_tail, after decode + NMS)
+}
 
-  // Segment head
+// Segment head of level l (P3 / P4 / P5): the three branches' first 3x3 convs as one launch, then per branch 3x3 -> 1x1
+void Detector::head_level_v8(int l, int n, hipStream_t s) {
   const char* feats[3] = {"p3", "p4", "p5"};
-  for (int l = 0; l < 3; ++l) {
-    const View f = V(feats[l]);
-    View t1 = V("t1"), t2 = V("t2");
-    t1.H = t2.H = f.H, t1.W = t2.W = f.W;
-    conv(head_first_[l], f, t1, 1, ACT_SILU, nullptr, n, s);
-    conv(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, ACT_SILU, nullptr, n, s);
-    conv(head_cls2_[l], t1.slice(64, 64), t2.slice(64, 64), 1, ACT_SILU, nullptr, n, s);
-    conv(head_coef2_[l], t1.slice(128, 32), t2.slice(128, 32), 1, ACT_SILU, nullptr, n, s);
-    View rh;
-    rh.p = rawhead_[l], rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
-    conv(head_box3_[l], t2.slice(0, 64), rh.slice(0, 64), 1, ACT_NONE, nullptr, n, s);
-    conv(head_cls3_[l], t2.slice(64, 64), rh.slice(RAW_CLS, cfg_.nc), 1, ACT_NONE, nullptr, n, s);
-    conv(head_coef3_[l], t2.slice(128, 32), rh.slice(RAW_COEF, nm_), 1, ACT_NONE, nullptr, n, s);
-  }
-  proto(head_, V("p3"), n, s);
+  const std::string ls = std::to_string(l);
+  const View f = view(feats[l]), t1 = view("t1_" + ls), t2 = view("t2_" + ls);
+  conv(head_first_[l], f, t1, 1, ACT_SILU, nullptr, n, s);
+  conv(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, ACT_SILU, nullptr, n, s);
+  conv(head_cls2_[l], t1.slice(64, 64), t2.slice(64, 64), 1, ACT_SILU, nullptr, n, s);
+  conv(head_coef2_[l], t1.slice(128, 32), t2.slice(128, 32), 1, ACT_SILU, nullptr, n, s);
+  View rh;
+  rh.p = rawhead_[l], rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
+  conv(head_box3_[l], t2.slice(0, 64), rh.slice(0, 64), 1, ACT_NONE, nullptr, n, s);
+  conv(head_cls3_[l], t2.slice(64, 64), rh.slice(RAW_CLS, cfg_.nc), 1, ACT_NONE, nullptr, n, s);
+  conv(head_coef3_[l], t2.slice(128, 32), rh.slice(RAW_COEF, nm_), 1, ACT_NONE, nullptr, n, s);
 }
 
 void Detector::raw(int n, float* pred, float* protos, hipStream_t s) {

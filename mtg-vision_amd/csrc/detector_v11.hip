@@ -311,8 +311,10 @@ void Detector::arena_v11() {
       {"cat16", s8, s8, 96}, {"tmp16", s8, s8, 16}, {"p3", s8, s8, c64},
       {"cat19", s16, s16, 192}, {"tmp19", s16, s16, 32}, {"p4", s16, s16, c128},
       {"cat22", s32, s32, 384}, {"kcat22", s32, s32, 128}, {"tmp22", s32, s32, 64}, {"p5", s32, s32, c256},
-      {"t1", s8, s8, 96}, {"t2", s8, s8, 96},                             // box + coefficient branches (largest level)
-      {"dwa", s8, s8, c256}, {"dwb", s8, s8, 64}, {"dwc", s8, s8, 64}, {"dwd", s8, s8, 64},  // class branch
+      // head temporaries per level (the levels' branches run concurrently): box + coefficient branches, class branch
+      {"t1_0", s8, s8, 96}, {"t2_0", s8, s8, 96}, {"dwa_0", s8, s8, c64}, {"dwb_0", s8, s8, 64}, {"dwc_0", s8, s8, 64}, {"dwd_0", s8, s8, 64},
+      {"t1_1", s16, s16, 96}, {"t2_1", s16, s16, 96}, {"dwa_1", s16, s16, c128}, {"dwb_1", s16, s16, 64}, {"dwc_1", s16, s16, 64}, {"dwd_1", s16, s16, 64},
+      {"t1_2", s32, s32, 96}, {"t2_2", s32, s32, 96}, {"dwa_2", s32, s32, c256}, {"dwb_2", s32, s32, 64}, {"dwc_2", s32, s32, 64}, {"dwd_2", s32, s32, 64},
       {"pr1", s8, s8, npr_}, {"pr2", s4, s4, npr_}, {"pr3", s4, s4, npr_}, {"protos", s4, s4, nm_},
   };
   size_t total = 0;
@@ -419,35 +421,37 @@ void Detector::forward_v11(const uint8_t* frames, int n, int flip, hipStream_t s
   c3k2(13, cat12, n13, n, s);
   if (!count_flops_) upsample2x_launch(n13.p, n13.ct, n13.co, cat15.p, cat15.ct, 0, n, n13.H, n13.W, c128, s);
   c3k2(16, cat15, V("p3"), n, s);
+  // the same fork-join as forward_v8: prototype branch and P3 / P4 heads beside the rest of the neck
+  proto(head_, V("p3"), n, fork_after(s, 0));
+  head_level_v11(0, n, fork_after(s, 1));
   conv(cw_.at("model.17"), V("p3"), cat18.slice(0, c64), 2, ACT_SILU, nullptr, n, s);
   c3k2(19, cat18, V("p4"), n, s);
+  head_level_v11(1, n, fork_after(s, 2));
   conv(cw_.at("model.20"), V("p4"), cat21.slice(0, c128), 2, ACT_SILU, nullptr, n, s);
   c3k2(22, cat21, V("p5"), n, s);
+  head_level_v11(2, n, s);
+  join_into(s, 1), join_into(s, 2);
+}
 
-  // Segment head
+// Segment head of level l: box + coefficient branches (first 3x3 convs merged), class branch of depthwise + pointwise pairs
+void Detector::head_level_v11(int l, int n, hipStream_t s) {
   const char* feats[3] = {"p3", "p4", "p5"};
-  for (int l = 0; l < 3; ++l) {
-    const View f = V(feats[l]);
-    View t1 = V("t1"), t2 = V("t2");
-    t1.H = t2.H = f.H, t1.W = t2.W = f.W;
-    View rh;
-    rh.p = rawhead_[l], rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
-    conv(head_bc_[l], f, t1, 1, ACT_SILU, nullptr, n, s);
-    conv(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, ACT_SILU, nullptr, n, s);
-    conv(head_coef2_[l], t1.slice(64, 32), t2.slice(64, 32), 1, ACT_SILU, nullptr, n, s);
-    conv(head_box3_[l], t2.slice(0, 64), rh.slice(0, 64), 1, ACT_NONE, nullptr, n, s);
-    conv(head_coef3_[l], t2.slice(64, 32), rh.slice(RAW_COEF, nm_), 1, ACT_NONE, nullptr, n, s);
-    // class branch: (depthwise 3x3, 1x1) twice, then the plain 1x1
-    View da = V("dwa"), db = V("dwb"), dc = V("dwc"), dd = V("dwd");
-    da.H = db.H = dc.H = dd.H = f.H, da.W = db.W = dc.W = dd.W = f.W;
-    const View da_l = da.slice(0, f.C);
-    dwconv(cls_dw1_[l], f, da_l, ACT_SILU, nullptr, 0, 0, n, s);
-    conv(cls_pw1_[l], da_l, db, 1, ACT_SILU, nullptr, n, s);
-    dwconv(cls_dw2_[l], db, dc, ACT_SILU, nullptr, 0, 0, n, s);
-    conv(cls_pw2_[l], dc, dd, 1, ACT_SILU, nullptr, n, s);
-    conv(head_cls3_[l], dd, rh.slice(RAW_CLS, cfg_.nc), 1, ACT_NONE, nullptr, n, s);
-  }
-  proto(head_, V("p3"), n, s);
+  const std::string ls = std::to_string(l);
+  const View f = view(feats[l]), t1 = view("t1_" + ls), t2 = view("t2_" + ls);
+  View rh;
+  rh.p = rawhead_[l], rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
+  conv(head_bc_[l], f, t1, 1, ACT_SILU, nullptr, n, s);
+  conv(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, ACT_SILU, nullptr, n, s);
+  conv(head_coef2_[l], t1.slice(64, 32), t2.slice(64, 32), 1, ACT_SILU, nullptr, n, s);
+  conv(head_box3_[l], t2.slice(0, 64), rh.slice(0, 64), 1, ACT_NONE, nullptr, n, s);
+  conv(head_coef3_[l], t2.slice(64, 32), rh.slice(RAW_COEF, nm_), 1, ACT_NONE, nullptr, n, s);
+  // class branch: (depthwise 3x3, 1x1) twice, then the plain 1x1
+  const View da = view("dwa_" + ls), db = view("dwb_" + ls), dc = view("dwc_" + ls), dd = view("dwd_" + ls);
+  dwconv(cls_dw1_[l], f, da, ACT_SILU, nullptr, 0, 0, n, s);
+  conv(cls_pw1_[l], da, db, 1, ACT_SILU, nullptr, n, s);
+  dwconv(cls_dw2_[l], db, dc, ACT_SILU, nullptr, 0, 0, n, s);
+  conv(cls_pw2_[l], dc, dd, 1, ACT_SILU, nullptr, n, s);
+  conv(head_cls3_[l], dd, rh.slice(RAW_CLS, cfg_.nc), 1, ACT_NONE, nullptr, n, s);
 }
 
 }  // namespace mtgv

@@ -43,6 +43,10 @@ struct GemmArgs {
   // output mapping: orow = (img*OH2 + oh*os + oy)*OW2 + ow*os + ox
   int ldo = 0, o_off = 0;
   int os = 1, oy = 0, ox = 0, OH2 = 1, OW2 = 1;
+  // os_nq > 0 (LDS-DMA kernel only): the N columns are os * os groups of os_nq channels and group q scatters to
+  // (oy, ox) = (q / os, q % os), channel n % os_nq - a whole ConvTranspose2d(k = s = os) as ONE launch that reads its
+  // input once (W rows ordered (kh, kw, cout); bias repeated per group).  os_nq % 8 == 0.
+  int os_nq = 0;
   int ldr = 0;
   int act = ACT_NONE;
 

@@ -366,6 +366,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
                "gemm: GRN partials planned for %d-row units, this launch writes %d-row units", a.grn_unit_rows, pl.bm());
   }
 
+  MTGV_CHECK(a.os_nq == 0, ERR_INVALID, "gemm: the grouped scatter epilogue (os_nq) exists on the LDS-DMA kernel only");
   GemmDev g;
   g.a = a;
   if (gemm_precision() == GEMM_PREC_F16X3 && g.a.W_split == nullptr && a.strideW == 0)

@@ -402,6 +402,12 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   g.d_kw = make_fastdiv((uint32_t)a.KW);
   g.remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
   g.os = a.os, g.oy = a.oy, g.ox = a.ox, g.OH2 = a.OH2, g.OW2 = a.OW2;
+  g.nq = a.os_nq;
+  g.d_nq = make_fastdiv((uint32_t)(a.os_nq > 0 ? a.os_nq : 1)), g.d_os = make_fastdiv((uint32_t)(a.os > 0 ? a.os : 1));
+  if (a.os_nq > 0)
+    MTGV_CHECK(g.remap && a.os_nq % 8 == 0 && a.N == a.os * a.os * a.os_nq && a.oy == 0 && a.ox == 0 && a.res == nullptr &&
+                   a.grn_part == nullptr,
+               ERR_INVALID, "gemm_sp: os_nq=%d does not describe a %dx%d scatter of N=%d columns", a.os_nq, a.os, a.os, a.N);
   if (a.grn_part != nullptr) {
     MTGV_CHECK(a.segmax >= (pl.unit_rows - 1) / g.hw + 2, ERR_INVALID, "gemm_sp: segmax %d too small", a.segmax);
     // the caller sized and will reduce the partial sums for the unit it planned with (gemm_grn_layout)

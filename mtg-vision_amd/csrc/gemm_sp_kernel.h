@@ -79,6 +79,8 @@ struct SpDev {
   FastDiv d_ohw, d_ow, d_cin, d_kw;
   // output row remap (ConvTranspose scatter): orow = (img*OH2 + oh*os + oy)*OW2 + ow*os + ox
   int remap = 0, os = 1, oy = 0, ox = 0, OH2 = 1, OW2 = 1;
+  int nq = 0;      // > 0: column group q = n / nq scatters to (oy, ox) = (q / os, q % os), channel n % nq (GemmArgs::os_nq)
+  FastDiv d_nq, d_os;
 };
 
 typedef const __attribute__((address_space(1))) void* sp_gptr;
@@ -827,8 +829,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
             const uint32_t rem = (uint32_t)m - img * (uint32_t)(g.OH * g.OW);
             const uint32_t oh = fdiv(rem, g.d_ow);
             const uint32_t ow = rem - oh * (uint32_t)g.OW;
-            const long orow = ((long)img * g.OH2 + oh * g.os + g.oy) * g.OW2 + ow * g.os + g.ox;
-            *reinterpret_cast<sp_f4*>(g.Out + orow * g.ldo + g.o_off + ncol0 + j * 32) = piece;
+            uint32_t oy = (uint32_t)g.oy, ox = (uint32_t)g.ox, cn = (uint32_t)(ncol0 + j * 32);
+            if (g.nq > 0) {  // whole ConvTranspose in one launch: this lane's column group names the output phase
+              const uint32_t q = fdiv(cn, g.d_nq);
+              cn -= q * (uint32_t)g.nq;
+              oy = fdiv(q, g.d_os);
+              ox = q - oy * (uint32_t)g.os;
+            }
+            const long orow = ((long)img * g.OH2 + oh * g.os + oy) * g.OW2 + ow * g.os + ox;
+            *reinterpret_cast<sp_f4*>(g.Out + orow * g.ldo + g.o_off + cn) = piece;
           } else if (!GEN || ncol0 + j * 32 + 4 <= g.N) {
             *reinterpret_cast<sp_f4*>(g.Out + o_lane + drow * g.ldo + j * 32) = piece;
           } else {  // ragged last quad (N % 4 != 0; f32 output without residual only)

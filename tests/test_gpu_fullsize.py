@@ -83,6 +83,42 @@ def test_detector_batch32_equals_single_frames():
         assert ((out["cls"][i, :n] >= 0) & (out["cls"][i, :n] < cfg.nc)).all()
 
 
+@pytest.mark.parametrize("arch", ["yolov8n-seg", "yolo11n-seg"])
+def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
+    """the forward's internal fork-join (prototype branch and P3 / P4 heads on library-owned streams beside the neck,
+    detector.hip) and the ConvTranspose as ONE scattered launch give the same bits as the serial, four-launch schedule -
+    raw predictions, prototypes, kept indices, boxes and mask logits - at batch 32, repeatedly (a race between the
+    branches would show as run-to-run differences)"""
+    import os
+
+    from mtgv import spec
+    from mtgv.detector import Detector
+
+    cfg = spec.DetectorConfig() if arch == "yolov8n-seg" else spec.yolo11_config()
+    det = Detector(cfg, spec.random_detector_state(cfg, 3), max_batch=32)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    frames = torch.randint(0, 256, (32, 640, 640, 3), generator=g, device="cuda", dtype=torch.uint8)
+
+    def run(fork, up1):
+        os.environ["MTGV_DET_FORK"], os.environ["MTGV_PROTO_UP1"] = fork, up1
+        try:
+            out = {k: (v.clone() if v is not None else None) for k, v in det.forward(frames, True, 8).items()}
+            pred, protos = det.raw_outputs(32)
+            out["pred"], out["protos"] = pred.clone(), protos.clone()
+            torch.cuda.synchronize()
+            return out
+        finally:
+            os.environ.pop("MTGV_DET_FORK", None), os.environ.pop("MTGV_PROTO_UP1", None)
+
+    base = run("0", "0")
+    assert (base["n_det"] > 0).all()
+    for rep in range(3):
+        for fork, up1 in (("1", "1"), ("1", "0"), ("0", "1")):
+            got = run(fork, up1)
+            for k in ("pred", "protos", "n_det", "keep_idx", "boxes", "conf", "cls", "mask_logits"):
+                assert torch.equal(got[k], base[k]), (k, fork, up1, rep)
+
+
 @pytest.mark.parametrize("quad_source", ["mask", "box"])
 def test_pipeline_full_step_properties(quad_source):
     """one bench-sized step (both crop dataflows; "mask" is the bench default): every card gets an id in range, crops are
