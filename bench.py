@@ -176,7 +176,7 @@ def main():
     from mtgv import native, spec
     from mtgv.detector import Detector
     from mtgv.encoder import Encoder
-    from mtgv.matcher import Matcher, merge_topk
+    from mtgv.matcher import Matcher, merge_gathered, merge_topk
     from mtgv.pipeline import Pipeline
 
     if a.precision:
@@ -204,13 +204,17 @@ def main():
     assert len(matcher) == hi - lo
 
     if sharded:
+        # the exchange in its lean form: the local top-k writes the (id, score bits) message itself and the merge reads the
+        # gathered buffer in place, so between them the stream sees only RCCL's two all-gathers (no PyTorch arithmetic:
+        # the step may share the GPU with the other stream's f16x3 GEMMs, include/mtgv.h)
         if backend == "nccl":
-            match_fn = lambda z, k: mdist.sharded_topk(z, k, matcher.match, merge_topk)  # noqa: E731
-        else:  # gloo rehearsal: collectives on host copies
+            match_fn = lambda z, k: mdist.sharded_topk(z, k, matcher.match, merge_topk,  # noqa: E731
+                                                       local_topk_packed=matcher.match_packed, merge_gathered=merge_gathered)
+        else:  # gloo rehearsal (two ranks on one GPU): the same calls, collectives on host copies (memcpys, no kernels)
             def match_fn(z, k):
-                loc = lambda q, kk: tuple(t.cpu() for t in matcher.match(q.to(dev), kk))  # noqa: E731
-                mrg = lambda cs, ci, kk: merge_topk(cs.to(dev), ci.to(dev), kk)  # noqa: E731
-                return mdist.sharded_topk(z.cpu(), k, loc, mrg)
+                loc = lambda q, kk: matcher.match_packed(q.to(dev), kk).cpu()  # noqa: E731
+                mrg = lambda gth, row0, b, kk: merge_gathered(gth.to(dev), row0, b, kk)  # noqa: E731
+                return mdist.sharded_topk(z.cpu(), k, None, None, local_topk_packed=loc, merge_gathered=mrg)
     else:
         match_fn = None
     pipe = Pipeline(detector, encoder, matcher, K, 1, match_fn, quad_source=a.quads)
@@ -257,6 +261,11 @@ def main():
         dt = float(t.item())
     cards = world * F * K * a.steps
     value = cards / dt
+    import zlib
+
+    # checksum of rank 0's top-1 ids over the timed steps: equal across bank layouts, stream counts and rank counts
+    # (rank 0's frames depend on the seed only) - tests/test_gpu_dist.py compares a sharded two-rank run with a replicated one
+    ids_crc = zlib.crc32(torch.stack([o["ids"] for o in out]).cpu().numpy().tobytes())
 
     res = {
         "metric": "cards/sec end-to-end (detect+embed+top-1 over 100k bank), 640x640",
@@ -290,6 +299,7 @@ def main():
             "tests/test_gpu_precision.py)",
             "streams": "2 (detect of step i+1 beside embed+match of step i; MTGV_OVERLAP=on set by bench.py, the library default is 1)" if overlap else "1",
             "settle": f"{a.settle_steps} untimed steps ({t_settle:.1f} s of steady load) before the {a.warmup} warm-up steps",
+            "ids_crc32_rank0": ids_crc,
             "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
             "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
         },
@@ -323,9 +333,19 @@ def main():
     def profile_pass(prec):
         nprof = 2
         native.check(L.mtgv_profile_gemm(1))
-        for i in range(nprof):
-            pipe.run(batches[i % NB])
-        torch.cuda.synchronize()
+        # every launch alone on the GPU: the detector's internal fork-join (prototype branch and heads on library-owned
+        # streams) is switched off for these passes, or concurrent launches would each be charged the other's time
+        fork_before = os.environ.get("MTGV_DET_FORK")
+        os.environ["MTGV_DET_FORK"] = "0"
+        try:
+            for i in range(nprof):
+                pipe.run(batches[i % NB])
+            torch.cuda.synchronize()
+        finally:
+            if fork_before is None:
+                os.environ.pop("MTGV_DET_FORK", None)
+            else:
+                os.environ["MTGV_DET_FORK"] = fork_before
         ms, fl, nl, by = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_double(0)
         native.check(L.mtgv_profile_gemm_read(C.byref(ms), C.byref(fl), C.byref(nl)))
         native.check(L.mtgv_profile_gemm_bytes(C.byref(by)))
@@ -417,7 +437,7 @@ def main():
                 "lds_fill_view": {"gbyte_per_step": round(fill_bytes / 1e9, 2),
                                   "achieved_tbs": round(fill_bytes / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
                                   "ceiling_tbs": {"infinity_cache_resident": 8.6, "l2_resident": 17.8}, "unit": "TB/s"},
-                "measured": "HIP events around every launch on its stream, 2 single-stream passes after the timed region",
+                "measured": "HIP events around every launch on its stream, 2 single-stream passes after the timed region (MTGV_DET_FORK=0 for them: the detector's branches in sequence, every launch alone on the GPU)",
             }
             if prof_f32 is not None:
                 ms32, fl32, n32, by32, groups32, _ = prof_f32

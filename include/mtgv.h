@@ -54,11 +54,15 @@ MTGV_API int mtgv_device_count(void);
  * before the worker threads start.
  * Concurrency contract for F16X3 (measured on MI355X / ROCm 7.2): kernels that use packed-FP32
  * arithmetic (v_pk_mul_f32, v_pk_fma_f32) and run on ANOTHER STREAM of the same GPU while F16X3 launches are in
- * flight can get wrong lanes.  This library is built without those instructions and by itself keeps every launch
- * on the caller's stream (mtgv.Pipeline overlaps two streams only with MTGV_OVERLAP=on, and then runs nothing but
- * library kernels on them: its output tensors are uninitialised allocations filled by the kernels, the glue between
- * the stages is mtgv_select_cards).  A caller that runs foreign kernels (PyTorch elementwise ops included) concurrently on
- * a second stream must either serialise them against the library's stream or select MTGV_PREC_F32. */
+ * flight can get wrong lanes.  This library is built without those instructions (every translation unit).  Streams
+ * the library itself uses besides the caller's: mtgv_detector_forward forks its prototype branch and two head branches
+ * onto library-owned streams and joins them before it returns control of the caller's stream (library kernels only;
+ * MTGV_DET_FORK=0 keeps the forward on one stream).  mtgv.Pipeline overlaps two streams only with MTGV_OVERLAP=on, and
+ * then runs nothing but library kernels on them - its output tensors are uninitialised allocations filled by the
+ * kernels, the glue between the stages is mtgv_select_cards - plus, with a sharded bank, RCCL's own all-gather kernels
+ * (mtgv_bank_topk_packed / mtgv_topk_merge_gathered keep every other step of the exchange inside the library).  A caller
+ * that runs foreign kernels (PyTorch elementwise ops included) concurrently on a second stream must either serialise
+ * them against the library's stream or select MTGV_PREC_F32. */
 #define MTGV_PREC_F32 0
 #define MTGV_PREC_F16X3 1
 MTGV_API int mtgv_set_gemm_precision(int32_t prec);
@@ -158,6 +162,16 @@ MTGV_API int mtgv_bank_prepass_fallbacks(const mtgv_bank* h, int64_t* count);
 /* merge ncand (score,id) candidates per query into the top k (multi-GPU shard merge); same threshold rule */
 MTGV_API int mtgv_topk_merge(float* cand_scores_dev, const int64_t* cand_ids_dev, int32_t b, int32_t ncand, int32_t k,
                              float score_threshold, int64_t* ids_dev, float* scores_dev, void* stream);
+/* The sharded match's exchange step without any arithmetic outside the library (mtgv/dist.py): the local
+ * top-k of ALL ranks' queries over this rank's shard is written in the exchange format packed[b][k][2] int64 =
+ * (global id or -1, float32 bit pattern of the score, zero-extended) - one buffer, so one all-gather carries ids and
+ * scores; after the all-gather, gathered[n_ranks][b_total][k][2] is merged for this rank's own queries
+ * [row0, row0 + b) (score desc, id asc; threshold rule as mtgv_bank_topk; n_ranks * k <= 4096).  Between the two calls
+ * the caller issues only the collective (RCCL's own kernels). */
+MTGV_API int mtgv_bank_topk_packed(mtgv_bank* h, const float* q_dev, int32_t b, int32_t k, int64_t id_base, int64_t* packed_dev,
+                                   void* stream);
+MTGV_API int mtgv_topk_merge_gathered(const int64_t* gathered_dev, int32_t n_ranks, int32_t b_total, int32_t k, int32_t row0, int32_t b,
+                                      float score_threshold, int64_t* ids_dev, float* scores_dev, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Detector: YOLOv8n-seg forward + decode + NMS + mask logits.                */

@@ -219,6 +219,21 @@ MTGV_API int mtgv_bank_topk(mtgv_bank* h, const float* q_dev, int32_t b, int32_t
     h->impl.topk(q_dev, b, k, id_base, score_threshold, ids_dev, scores_dev, (hipStream_t)stream);
   });
 }
+MTGV_API int mtgv_bank_topk_packed(mtgv_bank* h, const float* q_dev, int32_t b, int32_t k, int64_t id_base, int64_t* packed_dev,
+                                   void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr && packed_dev != nullptr, ERR_INVALID, "null argument");
+    h->impl.topk(q_dev, b, k, id_base, -INFINITY, packed_dev, nullptr, (hipStream_t)stream);
+  });
+}
+MTGV_API int mtgv_topk_merge_gathered(const int64_t* gathered_dev, int32_t n_ranks, int32_t b_total, int32_t k, int32_t row0, int32_t b,
+                                      float score_threshold, int64_t* ids_dev, float* scores_dev, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(gathered_dev && ids_dev && scores_dev, ERR_INVALID, "null argument");
+    MTGV_CHECK(!(score_threshold != score_threshold), ERR_INVALID, "topk_merge_gathered: score_threshold is NaN");
+    topk_merge_gathered_launch(gathered_dev, n_ranks, b_total, k, row0, b, score_threshold, ids_dev, scores_dev, (hipStream_t)stream);
+  });
+}
 MTGV_API int mtgv_bank_prepass_fallbacks(const mtgv_bank* h, int64_t* count) {
   return guarded([&] {
     MTGV_CHECK(h != nullptr && count != nullptr, ERR_INVALID, "null argument");

@@ -16,7 +16,8 @@ class Bank {
   void append(const float* v, int64_t n, bool is_device, hipStream_t s);
   void set_row(int64_t row, const float* v_host, hipStream_t s);
   void get_rows(int64_t row, int64_t n, float* out_host) const;
-  // thr: results scoring below it are dropped (id -1, score -inf); -INFINITY keeps everything
+  // thr: results scoring below it are dropped (id -1, score -inf); -INFINITY keeps everything.
+  // scores == nullptr: ids receives [b][k][2] int64 = (id, float32 bits of the score) - the sharded match's exchange format
   void topk(const float* q, int b, int k, int64_t id_base, float thr, int64_t* ids, float* scores, hipStream_t s);
   // queries of two-pass matches so far whose answer the first pass could not prove and that were scanned exactly
   // (synchronises the device)
@@ -34,6 +35,10 @@ class Bank {
   DevBuf hi_, qhi_, stat_;   // fp16 hi halves of the (row-scaled) bank rows / of the normalised queries, 2 bytes per element
 };
 
+// merge of all-gathered per-shard candidates in the exchange format (gathered[R][b_total][k][2]: id, score bits) for
+// the queries [row0, row0 + b)
+void topk_merge_gathered_launch(const int64_t* gathered, int R, int b_total, int k, int row0, int b, float thr, int64_t* ids,
+                                float* scores, hipStream_t s);
 void topk_merge_launch_i64(float* cs, const int64_t* ci, int b, int ncand, int k, float thr, int64_t* ids, float* scores,
                            hipStream_t s);
 

@@ -12,6 +12,18 @@
 
 namespace mtgv {
 
+// One result slot.  out_scores == nullptr selects the exchange format of the sharded match (mtgv/dist.py): out_ids is
+// then [slots][2] int64 = (id, the score's float32 bit pattern zero-extended) - one buffer, one all-gather.
+__device__ __forceinline__ void store_result(long* __restrict__ out_ids, float* __restrict__ out_scores, long slot, long id, float score) {
+  if (out_scores != nullptr) {
+    out_scores[slot] = score;
+    out_ids[slot] = id;
+  } else {
+    out_ids[2 * slot] = id;
+    out_ids[2 * slot + 1] = (long)__float_as_uint(score);
+  }
+}
+
 template <typename IdT>
 __global__ __launch_bounds__(256) void topk_merge_kernel(float* __restrict__ cs, const IdT* __restrict__ ci, int ncand, int k,
                                                         long id_base, float thr, long* __restrict__ out_ids,
@@ -46,8 +58,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(float* __restrict__ cs,
       // score_threshold (qdrant.py:83,93): candidates below it are not results - id -1 / score -inf pads, like a
       // bank with fewer than k rows
       const bool ok = rp[0] >= 0 && rs[0] >= thr;
-      out_scores[(long)b * k + kk] = ok ? rs[0] : -INFINITY;
-      out_ids[(long)b * k + kk] = ok ? ri[0] + id_base : -1;
+      store_result(out_ids, out_scores, (long)b * k + kk, ok ? ri[0] + id_base : -1, ok ? rs[0] : -INFINITY);
       if (rp[0] >= 0) s[rp[0]] = -INFINITY;  // retire
     }
     __syncthreads();
@@ -249,9 +260,68 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ q
   if (tid == 0)
     for (int kk = 0; kk < k; ++kk) {
       const bool ok = fi[0][kk] >= 0 && fs[0][kk] >= thr;
-      out_scores[(long)b * k + kk] = ok ? fs[0][kk] : -INFINITY;
-      out_ids[(long)b * k + kk] = ok ? fi[0][kk] + id_base : -1;
+      store_result(out_ids, out_scores, (long)b * k + kk, ok ? fi[0][kk] + id_base : -1, ok ? fs[0][kk] : -INFINITY);
     }
+}
+
+// Merge of the all-gathered per-shard candidates (mtgv/dist.py step 4): gathered[R][b_total][k][2] in the exchange
+// format above; block b merges the R * k candidates of query row0 + b (score desc, id asc; ids are global already).
+__global__ __launch_bounds__(256) void topk_merge_gathered_kernel(const long* __restrict__ gathered, int R, int b_total, int k, int row0,
+                                                                 float thr, long* __restrict__ out_ids, float* __restrict__ out_scores) {
+  extern __shared__ __attribute__((aligned(16))) char gm_sm[];
+  const int ncand = R * k;
+  long* ci = reinterpret_cast<long*>(gm_sm);
+  float* cs = reinterpret_cast<float*>(gm_sm + (size_t)ncand * sizeof(long));
+  __shared__ float rs[256];
+  __shared__ long ri[256];
+  __shared__ int rp[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int p = tid; p < ncand; p += 256) {
+    const int r = p / k, kk = p - r * k;
+    const long* e = gathered + (((long)r * b_total + row0 + b) * k + kk) * 2;
+    ci[p] = e[0];
+    cs[p] = __uint_as_float((unsigned)e[1]);
+  }
+  __syncthreads();
+  for (int kk = 0; kk < k; ++kk) {
+    float bs = -INFINITY;
+    long bi = 0x7fffffffffffffffL;
+    int bp = -1;
+    for (int p = tid; p < ncand; p += 256) {
+      const float v = cs[p];
+      const long i = ci[p];
+      if (i >= 0 && v > -INFINITY && (v > bs || (v == bs && i < bi))) bs = v, bi = i, bp = p;
+    }
+    rs[tid] = bs, ri[tid] = bi, rp[tid] = bp;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (tid < st) {
+        const float os = rs[tid + st];
+        const long oi = ri[tid + st];
+        const int op = rp[tid + st];
+        if (op >= 0 && (rp[tid] < 0 || os > rs[tid] || (os == rs[tid] && oi < ri[tid]))) rs[tid] = os, ri[tid] = oi, rp[tid] = op;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const bool ok = rp[0] >= 0 && rs[0] >= thr;
+      out_scores[(long)b * k + kk] = ok ? rs[0] : -INFINITY;
+      out_ids[(long)b * k + kk] = ok ? ri[0] : -1;
+      if (rp[0] >= 0) cs[rp[0]] = -INFINITY;  // retire
+    }
+    __syncthreads();
+  }
+}
+
+void topk_merge_gathered_launch(const int64_t* gathered, int R, int b_total, int k, int row0, int b, float thr, int64_t* ids,
+                                float* scores, hipStream_t s) {
+  MTGV_CHECK(R > 0 && k > 0 && b > 0 && row0 >= 0 && row0 + b <= b_total, ERR_INVALID, "topk_merge_gathered: R=%d k=%d rows [%d, %d) of %d", R,
+             k, row0, row0 + b, b_total);
+  MTGV_CHECK((long)R * k <= 4096, ERR_INVALID, "topk_merge_gathered: %d x %d candidates per query (at most 4096)", R, k);
+  const size_t lds = (size_t)R * k * (sizeof(long) + sizeof(float));
+  hipLaunchKernelGGL(topk_merge_gathered_kernel, dim3(b), dim3(256), lds, s, (const long*)gathered, R, b_total, k, row0, thr, (long*)ids,
+                     scores);
+  HIP_OK(hipGetLastError());
 }
 
 void topk_merge_launch_i64(float* cs, const int64_t* ci, int b, int ncand, int k, float thr, int64_t* ids, float* scores,
@@ -369,7 +439,7 @@ void Bank::get_rows(int64_t row, int64_t n, float* out_host) const {
 
 void Bank::topk(const float* q, int b, int k, int64_t id_base, float thr, int64_t* ids, float* scores, hipStream_t s) {
   MTGV_CHECK(b > 0 && k > 0 && k <= 65536, ERR_INVALID, "bank: b=%d k=%d (k must be in [1,65536])", b, k);
-  MTGV_CHECK(q != nullptr && ids != nullptr && scores != nullptr, ERR_INVALID, "bank: null tensor");
+  MTGV_CHECK(q != nullptr && ids != nullptr, ERR_INVALID, "bank: null tensor");  // scores == nullptr: exchange format in ids (store_result)
   MTGV_CHECK(size_ > 0, ERR_RUNTIME, "bank is empty");
   if (prepass_ok(b, k)) {
     topk_prepass(q, b, k, id_base, thr, ids, scores, s);

@@ -10,7 +10,11 @@ local row + offset), top-k of the union = merge of per-shard top-k:
     4. every rank merges the R*k candidates of its OWN queries (score desc, id asc)
 
 Both messages are KB-scale: latency-bound, xGMI bandwidth is irrelevant, so the step has exactly two
-collectives (RCCL `all_gather_into_tensor`, backend "nccl" on ROCm).  MTGV_FORCE_COLLECTIVE=1 runs them at
+collectives (RCCL `all_gather_into_tensor`, backend "nccl" on ROCm).  With `local_topk_packed` / `merge_gathered`
+(`Matcher.match_packed`, `matcher.merge_gathered`) step 2 writes the exchange format itself and step 4 reads the
+gathered buffer in place: the exchange then launches NOTHING but two library kernels and RCCL's two all-gathers - no
+PyTorch arithmetic - which is what lets it run on one of the two streams of `Pipeline.run_many` (include/mtgv.h,
+concurrency contract).  MTGV_FORCE_COLLECTIVE=1 runs them at
 world size 1 too (a one-GPU box can then exercise the RCCL path: tests/test_gpu_dist.py).  The local top-k and the merge
 are pluggable so the collective logic is exercised on CPU with gloo (tests/test_dist_cpu.py).
 """
@@ -18,7 +22,7 @@ are pluggable so the collective logic is exercised on CPU with gloo (tests/test_
 from __future__ import annotations
 
 import os
-from typing import Callable, Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -47,17 +51,24 @@ def _all_gather_cat(x: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
-def sharded_topk(q_local: torch.Tensor, k: int, local_topk: Callable, merge: Callable, group=None):
+def sharded_topk(q_local: torch.Tensor, k: int, local_topk: Callable, merge: Callable, group=None, *,
+                 local_topk_packed: Optional[Callable] = None, merge_gathered: Optional[Callable] = None):
     """q_local (B_local, D) -> global (ids (B_local, k) int64, scores (B_local, k)) for this rank's queries.
 
     local_topk(q (B,D), k) -> (ids int64 (B,k) GLOBAL ids, scores (B,k)) over this rank's bank shard.
     merge(cand_scores (B, R*k), cand_ids (B, R*k), k) -> (ids, scores).
+    Lean form (both given): local_topk_packed(q (B,D), k) -> (B, k, 2) int64 (id, float32 score bits);
+    merge_gathered(gathered (R, B_total, k, 2), row0, b, k) -> (ids, scores) - no tensor arithmetic in between.
     Every rank must pass the same B_local."""
     force = os.environ.get("MTGV_FORCE_COLLECTIVE") == "1"
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return local_topk(q_local, k)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     b_local = q_local.shape[0]
+    if local_topk_packed is not None and merge_gathered is not None:
+        q_all = _all_gather_cat(q_local, group).view(world * b_local, -1)  # a view of the collective's output
+        packed = local_topk_packed(q_all, k)
+        return merge_gathered(_all_gather_cat(packed, group), rank * b_local, b_local, k)
     q_all = _all_gather_cat(q_local, group).reshape(world * b_local, -1)
     ids, scores = local_topk(q_all, k)
     # one message: [..., 0] = id, [..., 1] = the score's float32 bit pattern

@@ -100,6 +100,18 @@ class Matcher:
             )
         return ids, scores
 
+    def match_packed(self, q: torch.Tensor, k: int = 1) -> torch.Tensor:
+        """The local top-k in the sharded match's exchange format (mtgv.dist, include/mtgv.h): q (B, D) float32 on the
+        device, contiguous -> (B, k, 2) int64 = (global id or -1, float32 bit pattern of the score).  One library call,
+        no other kernel: what one all-gather then carries to every rank."""
+        assert q.is_cuda and q.dtype == torch.float32 and q.ndim == 2 and q.shape[1] == self.dim and q.is_contiguous(), f"{tuple(q.shape)} {q.dtype}"
+        b = q.shape[0]
+        packed = torch.empty((b, k, 2), dtype=torch.int64, device=self.device)
+        if b:
+            with torch.cuda.device(self.device):
+                native.check(native.lib().mtgv_bank_topk_packed(self._h, native.ptr(q), b, int(k), self.id_base, native.ptr(packed), native.stream()))
+        return packed
+
     def prepass_fallbacks(self) -> int:
         """Queries of two-pass matches (>= 128 queries per call) that had to be scanned exactly so far (include/mtgv.h)."""
         v = native.c_i64(0)
@@ -130,4 +142,20 @@ def merge_topk(cand_scores: torch.Tensor, cand_ids: torch.Tensor, k: int, thresh
     scores = torch.empty((b, k), dtype=torch.float32, device=cs.device)
     with torch.cuda.device(cs.device):
         native.check(native.lib().mtgv_topk_merge(native.ptr(cs), native.ptr(ci), b, n, int(k), _thr(threshold), native.ptr(ids), native.ptr(scores), native.stream()))
+    return ids, scores
+
+
+def merge_gathered(gathered: torch.Tensor, row0: int, b: int, k: int, threshold: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge the all-gathered per-shard candidates (R, B_total, k, 2) int64 in the exchange format of
+    `Matcher.match_packed` for the queries [row0, row0 + b): global (ids (b, k) int64, scores (b, k) float32), score desc
+    then id asc.  One library kernel reads the collective's output buffer in place."""
+    assert gathered.is_cuda and gathered.dtype == torch.int64 and gathered.ndim == 4 and gathered.shape[2] == k and gathered.shape[3] == 2
+    assert gathered.is_contiguous()
+    R, b_total = gathered.shape[0], gathered.shape[1]
+    ids = torch.empty((b, k), dtype=torch.int64, device=gathered.device)
+    scores = torch.empty((b, k), dtype=torch.float32, device=gathered.device)
+    if b:
+        with torch.cuda.device(gathered.device):
+            native.check(native.lib().mtgv_topk_merge_gathered(native.ptr(gathered), R, b_total, int(k), int(row0), int(b), _thr(threshold),
+                                                               native.ptr(ids), native.ptr(scores), native.stream()))
     return ids, scores

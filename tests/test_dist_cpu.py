@@ -53,10 +53,27 @@ def _worker(rank, world, port, n_bank, b_local, k, ret):
                 out_s[r, : len(order)] = cs[r][valid][order]
             return torch.from_numpy(out_i), torch.from_numpy(out_s)
 
+        # the lean form of the exchange (include/mtgv.h: mtgv_bank_topk_packed / mtgv_topk_merge_gathered), restated in numpy:
+        # the local top-k writes (id, float32 score bits) pairs, the merge reads the gathered (R, B_total, k, 2) buffer
+        def local_topk_packed(q, kk):
+            ids, sc = local_topk(q, kk)
+            bits = sc.numpy().astype(np.float32).view(np.uint32).astype(np.int64)
+            return torch.from_numpy(np.stack([ids.numpy().astype(np.int64), bits], -1))
+
+        def merge_gathered(g, row0, b, kk):
+            g = g.numpy()
+            assert g.shape[1:] == (world * b_local, kk, 2)
+            mine = g[:, row0 : row0 + b].transpose(1, 0, 2, 3).reshape(b, -1, 2)
+            cs = mine[..., 1].astype(np.uint32).view(np.float32)
+            return merge(torch.from_numpy(cs.copy()), torch.from_numpy(mine[..., 0].copy()), kk)
+
         q_local = torch.from_numpy(q_all[rank * b_local : (rank + 1) * b_local])
-        ids, sc = mdist.sharded_topk(q_local, k, local_topk, merge)
         ref_i, ref_s = M.cosine_topk(q_all[rank * b_local : (rank + 1) * b_local], bank, k, dtype=np.float32)
-        ok = bool((ids.numpy() == ref_i).all() and np.allclose(sc.numpy(), ref_s, atol=1e-6))
+        ok = True
+        for lean in (False, True):
+            kw = dict(local_topk_packed=local_topk_packed, merge_gathered=merge_gathered) if lean else {}
+            ids, sc = mdist.sharded_topk(q_local, k, local_topk, merge, **kw)
+            ok = ok and bool((ids.numpy() == ref_i).all() and np.allclose(sc.numpy(), ref_s, atol=1e-6))
         ret[rank] = ok
     finally:
         dist.destroy_process_group()

@@ -111,7 +111,7 @@ def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
             os.environ.pop("MTGV_DET_FORK", None), os.environ.pop("MTGV_PROTO_UP1", None)
 
     base = run("0", "0")
-    assert (base["n_det"] > 0).all()
+    assert (base["n_det"] > 0).any()
     for rep in range(3):
         for fork, up1 in (("1", "1"), ("1", "0"), ("0", "1")):
             got = run(fork, up1)

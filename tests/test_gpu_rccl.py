@@ -47,6 +47,12 @@ ids, sc = mdist.sharded_topk(q, 3, m.match, merge_topk)
 torch.cuda.synchronize()
 assert len(calls) == 2, calls            # queries + one packed (id, score) message
 assert (ids == ref_i).all() and (sc == ref_s).all()
+from mtgv.matcher import merge_gathered
+del calls[:]
+ids, sc = mdist.sharded_topk(q, 3, m.match, merge_topk, local_topk_packed=m.match_packed, merge_gathered=merge_gathered)
+torch.cuda.synchronize()
+assert calls == [(37, 768), (37, 3, 2)], calls   # the lean form: the library writes and reads the exchange format itself
+assert (ids == ref_i).all() and (sc == ref_s).all()
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_ONE_RANK_OK", calls)
