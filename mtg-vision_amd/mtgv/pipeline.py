@@ -26,6 +26,70 @@ _PAD_BOXES = torch.tensor(
 )
 
 
+class HostFrames:
+    """Frame batches that arrive in host memory, as the reference's do (one JPEG per websocket message decoded on the host,
+    mtgvision/server.py:272-280): the batches are copied to the GPU on a third stream - hipMemcpyAsync from pinned memory,
+    the copy engine, no kernel - into a small ring of device buffers while the previous batches are being processed.
+
+        src = HostFrames(pinned_batches, device)
+        outs = pipe.run_many(src.leases(n_steps))
+
+    A lease's `tensor()` makes the consuming stream wait for its copy; `done()` (called by the pipeline after the last
+    stage that reads the frames - the de-warp) lets the buffer be overwritten by the copy `depth` batches later."""
+
+    def __init__(self, host_batches, device, depth: int = 3):
+        assert depth >= 2 and len(host_batches) > 0
+        self.host = [b if b.is_pinned() else b.pin_memory() for b in host_batches]
+        self.device = torch.device(device)
+        self.depth = depth
+        self.s_copy = torch.cuda.Stream(self.device)
+        self.bufs = [torch.empty(self.host[0].shape, dtype=self.host[0].dtype, device=self.device) for _ in range(depth)]
+        self.copied = [torch.cuda.Event() for _ in range(depth)]
+        self.released = [None] * depth
+        self._issued = 0
+
+    class _Lease:
+        def __init__(self, src, slot):
+            self.src, self.slot = src, slot
+
+        def tensor(self) -> torch.Tensor:
+            torch.cuda.current_stream(self.src.device).wait_event(self.src.copied[self.slot])
+            return self.src.bufs[self.slot]
+
+        def done(self) -> None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.src.device))
+            self.src.released[self.slot] = ev
+
+    def _issue(self):
+        j = self._issued % self.depth
+        h = self.host[self._issued % len(self.host)]
+        self._issued += 1
+        with torch.cuda.stream(self.s_copy):
+            if self.released[j] is not None:
+                self.s_copy.wait_event(self.released[j])  # the batch that used this buffer has been de-warped
+            self.bufs[j].copy_(h, non_blocking=True)
+            self.copied[j].record(self.s_copy)
+        return HostFrames._Lease(self, j)
+
+    def leases(self, n: int):
+        """n leases; copies run one to two batches ahead of their consumer.  Copy i + 1 is issued when lease i is handed
+        out (i >= 1): its buffer was last used by lease i - 2, whose done() the pipeline recorded one batch ago - so the
+        event the copy has to wait for always exists by then."""
+        ahead = [self._issue() for _ in range(min(n, self.depth - 1))]
+        issued = len(ahead)
+        for i in range(n):
+            if i > 0 and issued < n:
+                ahead.append(self._issue())
+                issued += 1
+            yield ahead.pop(0)
+
+
+def _frames_of(item):
+    """(tensor, lease or None) of a batch handed to run / run_many: a device tensor, or a lease of HostFrames"""
+    return (item.tensor(), item) if hasattr(item, "tensor") and hasattr(item, "done") else (item, None)
+
+
 class Pipeline:
     def __init__(self, detector: Detector, encoder: Encoder, matcher, cards_per_frame: int = 8, top_k: int = 1,
                  match_fn: Optional[Callable] = None, quad_source: str = "box"):
@@ -41,7 +105,7 @@ class Pipeline:
         reps = (self.K + _PAD_BOXES.shape[0] - 1) // _PAD_BOXES.shape[0]
         self._pad = _PAD_BOXES.repeat(reps, 1)[: self.K].to(detector.device).contiguous()
 
-    def _embed_match(self, frames_u8: torch.Tensor, det):
+    def _embed_match(self, frames_u8: torch.Tensor, det, lease=None):
         F, K = frames_u8.shape[0], self.K
         # the K highest-confidence detections per frame (NMS output is score-descending), pad boxes where a frame has
         # fewer; every step of the glue is a library kernel (no PyTorch arithmetic on the streams of the step)
@@ -56,6 +120,8 @@ class Pipeline:
             quads, _ = mask_quads_from_logits(ml.view(F * K, *ml.shape[-2:]), sel)
         boxes = sel.view(F, K, 4)
         crops = warp_quads(frames_u8, quads, frame_idx, self.encoder.cfg.image_hw, 0.05)
+        if lease is not None:
+            lease.done()  # the de-warp is the last reader of the frames
         z = self.encoder.encode(crops)
         ids, scores = self.match_fn(z, self.top_k)
         return {
@@ -88,6 +154,8 @@ class Pipeline:
         the library, kernels sharing a CU with the split-precision GEMM of the other stream sporadically lost a
         packed result in one 16-lane group; the library is built without those instructions - build.py, DESIGN.md
         section 5 - and tests/test_gpu_overlap.py guards the combination.)"""
+        import itertools
+
         if not self.overlap_enabled():
             return [self.run(frames, flip_rgb) for frames in batches]
         dev = self.detector.device
@@ -97,22 +165,23 @@ class Pipeline:
         self._s_det.wait_stream(cur)
         self._s_enc.wait_stream(cur)
         outs, pending = [], None
-        for frames in list(batches) + [None]:
+        for item in itertools.chain(batches, [None]):  # (lazily: a HostFrames lease is issued when its turn comes)
             nxt = None
-            if frames is not None:
+            if item is not None:
                 with torch.cuda.stream(self._s_det):
+                    frames, lease = _frames_of(item)
                     det = self.detector.forward(frames, flip_rgb, mask_rows=self.K)
                     ev = torch.cuda.Event()
                     ev.record(self._s_det)
-                nxt = (frames, det, ev)
+                nxt = (frames, det, ev, lease)
             if pending is not None:
-                pf, pdet, pev = pending
+                pf, pdet, pev, please = pending
                 with torch.cuda.stream(self._s_enc):
                     self._s_enc.wait_event(pev)
                     for t in pdet.values():
                         if t is not None:
                             t.record_stream(self._s_enc)
-                    outs.append(self._embed_match(pf, pdet))
+                    outs.append(self._embed_match(pf, pdet, please))
             pending = nxt
         cur.wait_stream(self._s_det)
         cur.wait_stream(self._s_enc)
@@ -124,5 +193,6 @@ class Pipeline:
     def run(self, frames_u8: torch.Tensor, flip_rgb: bool = True):
         """frames (F, 640, 640, 3) uint8 on the GPU -> dict with ids (F, K, top_k) int64, scores, n_det (F,)
         and the intermediate crops / embeddings (device tensors)."""
+        frames_u8, lease = _frames_of(frames_u8)
         det = self.detector.forward(frames_u8, flip_rgb, mask_rows=self.K)
-        return self._embed_match(frames_u8, det)
+        return self._embed_match(frames_u8, det, lease)

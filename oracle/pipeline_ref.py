@@ -37,16 +37,36 @@ def select_boxes(dets, K):
     return np.stack(out)
 
 
-def run(det_params, det_cfg, enc_params, enc_cfg, bank, frames_u8, K=8, top_k=1, flip_rgb=True, boxes=None, quads=None):
+def mask_quads_of(dets, boxes, K, imgsz):
+    """the reference's dataflow (od_export.py:52-111): the oriented quadrilateral of every selected detection's mask
+    (quad_ref: hull + approxPolyN + orientation); slots without a detection, and empty masks, keep their box"""
+    from . import quad_ref
+
+    quads = boxes_to_quads(boxes.reshape(-1, 4)).reshape(len(dets), K, 4, 2).copy()
+    for f, d in enumerate(dets):
+        n = min(K, len(d["keep_idx"]))
+        if n == 0:
+            continue
+        masks = detector_ref.masks_binary(d["mask_logits"][:n], imgsz)
+        q, ok = quad_ref.mask_quads(masks, boxes[f, :n])
+        quads[f, :n][ok > 0] = q[ok > 0]
+    return quads.reshape(len(dets) * K, 4, 2)
+
+
+def run(det_params, det_cfg, enc_params, enc_cfg, bank, frames_u8, K=8, top_k=1, flip_rgb=True, boxes=None, quads=None,
+        quad_source="box"):
     """-> dict(ids (F,K,top_k), scores, boxes (F,K,4), crops (F*K,h,w,3) u8, z (F*K, z))
 
     `boxes` (and `quads` (F*K,4,2), e.g. from quad_ref.mask_quads) may be supplied to check the later stages on
-    identical inputs."""
+    identical inputs.  quad_source "mask" (when the detector runs here): crops are the mask quadrilaterals, as in
+    bench.py's default GPU dataflow; "box": the detection boxes."""
     F = frames_u8.shape[0]
     dets = None
     if boxes is None:
         dets, _, _ = detector_ref.detect(det_params, det_cfg, frames_u8, flip_rgb)
         boxes = select_boxes(dets, K)
+    if quads is None and quad_source == "mask" and dets is not None:
+        quads = mask_quads_of(dets, boxes, K, det_cfg.imgsz)
     if quads is None:
         quads = boxes_to_quads(boxes.reshape(F * K, 4))
     h, w = enc_cfg.image_hw

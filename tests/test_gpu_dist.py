@@ -87,15 +87,15 @@ def test_exchange_format_roundtrip():
     from mtgv.matcher import Matcher, merge_gathered
 
     g = torch.Generator(device="cuda").manual_seed(8)
-    bank = torch.randn((9_001, 768), generator=g, device="cuda")
-    q = torch.randn((140, 768), generator=g, device="cuda")  # >= 128 queries: the two-pass kernel writes the format too
-    full = Matcher(768, capacity=9_001)
+    bank = torch.randn((13_001, 768), generator=g, device="cuda")  # shards of >= 4096 rows: full bank and shards both take the two-pass
+    q = torch.randn((140, 768), generator=g, device="cuda")        # kernel at >= 128 queries (exact float64 re-rank: identical score bits)
+    full = Matcher(768, capacity=13_001)
     full.add(bank)
     for k in (1, 3):
         ids, sc = full.match(q, k)
         parts = []
         for r in range(3):
-            lo, hi = shard_rows(9_001, r, 3)
+            lo, hi = shard_rows(13_001, r, 3)
             m = Matcher(768, capacity=hi - lo, id_base=lo)
             m.add(bank[lo:hi])
             p = m.match_packed(q, k)
