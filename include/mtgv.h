@@ -281,6 +281,13 @@ MTGV_API int mtgv_warp_quads(const uint8_t* frames_dev, int32_t nf, int32_t fh, 
 MTGV_API int mtgv_make_cropped(const uint8_t* images_dev, const int64_t* offsets_dev, const int32_t* hw_dev, int32_t n,
                                int32_t out_h, int32_t out_w, float* out_dev, void* stream);
 
+/* ultralytics LetterBox in front of the detector (behind CardSegmenter.__call__, mtgvision/od_export.py:147-150): the (h, w, 3)
+ * uint8 frame at src_dev resampled bilinearly (align_corners = false form) to (nh, nw), placed at (top, left) of the
+ * size x size x 3 uint8 image at dst_dev, the rest filled with pad_value (114 upstream).  The caller computes the geometry
+ * (mtgv.detector.letterbox_geometry: r = min(size / h, size / w), nh = round(h r), ...). */
+MTGV_API int mtgv_letterbox_u8(const uint8_t* src_dev, int32_t h, int32_t w, uint8_t* dst_dev, int32_t size, int32_t nh, int32_t nw,
+                               int32_t top, int32_t left, int32_t pad_value, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Single ops (unit-test and composition surface; same kernels the handles use) */
 /* ------------------------------------------------------------------------- */

@@ -18,6 +18,8 @@
 // per pixel as (a0 + a1) + (a2 + a3) per channel quad (two DPP steps), then the quads in ascending order by one
 // thread; two-pass variance.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "sp8.h"
 
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(C* G) void dwconv7_ln_stream_kernel(const float* __
 #pragma unroll
   for (int j = 0; j < TW + 6; ++j) jok[j] = (w0 + j - 3) >= 0 && (w0 + j - 3) < W;
   const int lane_off = (w0 - 3) * C + ch;  // float offset of this thread's first column inside a row (may be negative: masked)
+  const bool wave_edge = __builtin_amdgcn_ballot_w64(g == 0 || g == G - 1) != 0;
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -91,29 +94,36 @@ __global__ __launch_bounds__(C* G) void dwconv7_ln_stream_kernel(const float* __
     for (int t = 0; t < TH; ++t)
 #pragma unroll
       for (int j = 0; j < TW; ++j) acc[t][j] = bv;
+    // MASK: this wave holds lanes of the first or last strip (columns outside the image read as zero); the other waves
+    // run the same loop without the selects
+    auto conv_rows = [&](auto MASK_T) {
+      constexpr bool MASK = decltype(MASK_T)::value;
 #pragma unroll
-    for (int ir = 0; ir < TH + 6; ++ir) {
-      const int ih = h0 - 3 + ir;
-      if (ih < 0 || ih >= H) continue;  // (wave-uniform)
-      int slot = sbase + ir;
-      slot = slot >= R ? slot - R : slot;
-      const float* const rowp = ring + slot * ROWF + lane_off;
-      float r[TW + 6];
+      for (int ir = 0; ir < TH + 6; ++ir) {
+        const int ih = h0 - 3 + ir;
+        if (ih < 0 || ih >= H) continue;  // (wave-uniform)
+        int slot = sbase + ir;
+        slot = slot >= R ? slot - R : slot;
+        const float* const rowp = ring + slot * ROWF + lane_off;
+        float r[TW + 6];
 #pragma unroll
-      for (int j = 0; j < TW + 6; ++j) {
-        const float v = rowp[j * C];  // (an address below the ring for masked columns of strip 0 stays inside LDS: unused)
-        r[j] = (j >= 3 && j < TW + 3) ? v : (jok[j] ? v : 0.f);
+        for (int j = 0; j < TW + 6; ++j) {
+          const float v = rowp[j * C];  // (an address below the ring for masked columns of strip 0 stays inside LDS: unused)
+          r[j] = (!MASK || (j >= 3 && j < TW + 3)) ? v : (jok[j] ? v : 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < TH; ++t) {
+          const int kh = ir - t;  // output row h0 + t sees this input row as its tap row kh
+          if (kh < 0 || kh > 6) continue;
+#pragma unroll
+          for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+            for (int j = 0; j < TW; ++j) acc[t][j] = __builtin_fmaf(r[j + kw], wt[kh * 7 + kw], acc[t][j]);
+        }
       }
-#pragma unroll
-      for (int t = 0; t < TH; ++t) {
-        const int kh = ir - t;  // output row h0 + t sees this input row as its tap row kh
-        if (kh < 0 || kh > 6) continue;
-#pragma unroll
-        for (int kw = 0; kw < 7; ++kw)
-#pragma unroll
-          for (int j = 0; j < TW; ++j) acc[t][j] = __builtin_fmaf(r[j + kw], wt[kh * 7 + kw], acc[t][j]);
-      }
-    }
+    };
+    if (wave_edge) conv_rows(std::true_type{});
+    else conv_rows(std::false_type{});
     sbase += TH;
     sbase = sbase >= R ? sbase - R : sbase;
 
@@ -169,8 +179,11 @@ __global__ __launch_bounds__(C* G) void dwconv7_ln_stream_kernel(const float* __
 #pragma unroll
       for (int j = 0; j < TW; ++j) {
         const float rstd = stat[(g * P + t * TW + j) * 2 + 1];
-        const float o = (acc[t][j] - mean[t][j]) * rstd * lw + lb;
+        float o = (acc[t][j] - mean[t][j]) * rstd * lw + lb;
         if (SP8) {
+          // (o as an f32 value first: left to itself the compiler converts the un-rounded FMA straight to fp16 -
+          // v_fma_mixlo_f16 - and the hi half then differs from the quad kernels' in the double-rounding cases)
+          asm volatile("" : "+v"(o));
           // chunk of 8 channels = [8 fp16 hi][8 fp16 lo]: a lane pair (2i, 2i + 1) trades halves so that the even lane
           // holds the pair's two hi halves and the odd lane its two lo halves - one coalesced dword store per pixel
           const _Float16 hi = (_Float16)o;

@@ -55,10 +55,61 @@ __global__ __launch_bounds__(256) void make_cropped_kernel(const uint8_t* __rest
   }
 }
 
+// ultralytics LetterBox ahead of the detector (behind CardSegmenter.__call__, od_export.py:147-150): the frame scaled to
+// fit size x size (bilinear; cv2.resize(INTER_LINEAR) upstream - absent here, parity unpinned), centred, the border
+// filled with pad_value.  Thread = one output pixel.  The resample is the align_corners = False form PyTorch's
+// interpolate uses, in float32 in this order: src = scale * (dst + 0.5) - 0.5 clamped at 0, h0 * (w0 * v00 + w1 * v01) +
+// h1 * (w0 * v10 + w1 * v11), rounded to nearest even, clamped to [0, 255] (oracle/resize_ref.py: letterbox).  A frame
+// that already has the target size is copied exactly (all weights 0 or 1).
+__global__ __launch_bounds__(256) void letterbox_u8_kernel(const uint8_t* __restrict__ src, int h, int w, uint8_t* __restrict__ dst, int size,
+                                                          int nh, int nw, int top, int left, int pad_value) {
+#pragma clang fp contract(off)
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= size * size) return;
+  const int y = idx / size, x = idx - y * size;
+  uint8_t* o = dst + (long)idx * 3;
+  const int ry = y - top, rx = x - left;
+  if (ry < 0 || ry >= nh || rx < 0 || rx >= nw) {
+    o[0] = o[1] = o[2] = (uint8_t)pad_value;
+    return;
+  }
+  const float sch = (float)h / (float)nh, scw = (float)w / (float)nw;
+  float sy = sch * ((float)ry + 0.5f) - 0.5f, sx = scw * ((float)rx + 0.5f) - 0.5f;
+  sy = sy < 0.f ? 0.f : sy;
+  sx = sx < 0.f ? 0.f : sx;
+  int y0 = (int)sy, x0 = (int)sx;
+  y0 = y0 > h - 1 ? h - 1 : y0;
+  x0 = x0 > w - 1 ? w - 1 : x0;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+  const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+  const uint8_t *p00 = src + ((long)y0 * w + x0) * 3, *p01 = src + ((long)y0 * w + x1) * 3, *p10 = src + ((long)y1 * w + x0) * 3,
+                *p11 = src + ((long)y1 * w + x1) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = ly0 * (lx0 * (float)p00[c] + lx1 * (float)p01[c]) + ly1 * (lx0 * (float)p10[c] + lx1 * (float)p11[c]);
+    float r = rintf(v);
+    r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+    o[c] = (uint8_t)r;
+  }
+}
+
 }  // namespace mtgv
 
 using namespace mtgv;
 extern "C" {
+MTGV_API int mtgv_letterbox_u8(const uint8_t* src_dev, int32_t h, int32_t w, uint8_t* dst_dev, int32_t size, int32_t nh, int32_t nw,
+                               int32_t top, int32_t left, int32_t pad_value, void* stream) {
+  return guarded([&] {
+    MTGV_CHECK(src_dev && dst_dev, ERR_INVALID, "null argument");
+    MTGV_CHECK(h > 0 && w > 0 && size > 0 && nh > 0 && nw > 0 && top >= 0 && left >= 0 && top + nh <= size && left + nw <= size &&
+                   pad_value >= 0 && pad_value <= 255,
+               ERR_INVALID, "letterbox: %dx%d -> %dx%d at (%d, %d) of %d", h, w, nh, nw, top, left, size);
+    hipLaunchKernelGGL(letterbox_u8_kernel, dim3((size * size + 255) / 256), dim3(256), 0, (hipStream_t)stream, src_dev, h, w, dst_dev, size,
+                       nh, nw, top, left, pad_value);
+    HIP_OK(hipGetLastError());
+  });
+}
 MTGV_API int mtgv_make_cropped(const uint8_t* images_dev, const int64_t* offsets_dev, const int32_t* hw_dev, int32_t n,
                                int32_t out_h, int32_t out_w, float* out_dev, void* stream) {
   return guarded([&] {

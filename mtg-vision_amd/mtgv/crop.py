@@ -12,9 +12,17 @@ import torch
 from . import native
 
 
-def warp_quads(frames: torch.Tensor, quads: torch.Tensor, frame_idx: torch.Tensor, out_size_hw=(192, 128), expand_ratio: float = 0.05) -> torch.Tensor:
+def warp_workspace(nq: int, device) -> torch.Tensor:
+    """device scratch for `warp_quads` of up to nq quads (the 3 x 3 coefficients in float64): callers on a hot path allocate
+    it once (Pipeline does) and pass it in"""
+    return torch.empty((int(native.lib().mtgv_warp_workspace_bytes(nq)) + 7) // 8, dtype=torch.float64, device=device)
+
+
+def warp_quads(frames: torch.Tensor, quads: torch.Tensor, frame_idx: torch.Tensor, out_size_hw=(192, 128), expand_ratio: float = 0.05,
+               workspace: torch.Tensor = None) -> torch.Tensor:
     """frames (nf, H, W, 3) uint8; quads (nq, 4, 2) float32 corner pixels (tl, tr, br, bl order of the
-    card); frame_idx (nq,) int32 -> crops (nq, out_h, out_w, 3) uint8, all on the GPU."""
+    card); frame_idx (nq,) int32 -> crops (nq, out_h, out_w, 3) uint8, all on the GPU.  `workspace`: see warp_workspace
+    (allocated per call when absent or too small)."""
     native.require_gpu()
     assert frames.is_cuda and frames.dtype == torch.uint8 and frames.ndim == 4 and frames.shape[-1] == 3
     nq = quads.shape[0]
@@ -26,7 +34,9 @@ def warp_quads(frames: torch.Tensor, quads: torch.Tensor, frame_idx: torch.Tenso
     frame_idx = frame_idx.to(frames.device, torch.int32).contiguous()
     assert tuple(quads.shape) == (nq, 4, 2) and tuple(frame_idx.shape) == (nq,)
     L = native.lib()
-    ws = torch.empty((int(L.mtgv_warp_workspace_bytes(nq)) + 7) // 8, dtype=torch.float64, device=frames.device)
+    ws = workspace
+    if ws is None or ws.device != frames.device or ws.numel() * 8 < int(L.mtgv_warp_workspace_bytes(nq)):
+        ws = warp_workspace(nq, frames.device)
     with torch.cuda.device(frames.device):
         native.check(
             L.mtgv_warp_quads(native.ptr(frames.contiguous()), frames.shape[0], frames.shape[1], frames.shape[2], native.ptr(quads), native.ptr(frame_idx),
@@ -71,8 +81,8 @@ def mask_quads(masks_u8: torch.Tensor, boxes_xyxy: torch.Tensor = None, extents:
     native.require_gpu()
     assert masks_u8.is_cuda and masks_u8.dtype == torch.uint8 and masks_u8.ndim == 3, f"{tuple(masks_u8.shape)} {masks_u8.dtype}"
     n, h, w = masks_u8.shape
-    quads = torch.zeros((n, 4, 2), dtype=torch.float32, device=masks_u8.device)
-    ok = torch.zeros((n,), dtype=torch.int32, device=masks_u8.device)
+    quads = torch.empty((n, 4, 2), dtype=torch.float32, device=masks_u8.device)  # the kernel writes every row (an empty
+    ok = torch.empty((n,), dtype=torch.int32, device=masks_u8.device)             # mask: its box or zeros, ok = 0)
     ext = torch.empty((n, h, 2), dtype=torch.int32, device=masks_u8.device) if extents else None
     if n == 0:
         return (quads, ok, ext) if extents else (quads, ok)

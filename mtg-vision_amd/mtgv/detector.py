@@ -28,6 +28,28 @@ class Detections:
     mask_logits: Optional[torch.Tensor]  # (n, 160, 160) float32, zero outside the box
 
 
+def letterbox_geometry(h: int, w: int, size: int = 640):
+    """ultralytics LetterBox geometry: (ratio, nh, nw, top, left) - scale to fit, centre (round(d - 0.1) like upstream)"""
+    r = min(size / h, size / w)
+    nh, nw = int(round(h * r)), int(round(w * r))
+    dh, dw = (size - nh) / 2, (size - nw) / 2
+    return r, nh, nw, int(round(dh - 0.1)), int(round(dw - 0.1))
+
+
+def letterbox_device(frame: torch.Tensor, size: int = 640, pad_value: int = 114):
+    """(H, W, 3) uint8 frame on the GPU -> ((1, size, size, 3) uint8 letterboxed image on the GPU, ratio, (left, top)): one
+    library kernel (resize.hip: letterbox_u8_kernel) instead of a host resample + pad."""
+    native.require_gpu()
+    assert frame.is_cuda and frame.dtype == torch.uint8 and frame.ndim == 3 and frame.shape[-1] == 3, f"{tuple(frame.shape)} {frame.dtype}"
+    h, w = int(frame.shape[0]), int(frame.shape[1])
+    r, nh, nw, top, left = letterbox_geometry(h, w, size)
+    out = torch.empty((1, size, size, 3), dtype=torch.uint8, device=frame.device)
+    with torch.cuda.device(frame.device):
+        native.check(native.lib().mtgv_letterbox_u8(native.ptr(frame.contiguous()), h, w, native.ptr(out), size, nh, nw, top, left, pad_value,
+                                                    native.stream()))
+    return out, r, (left, top)
+
+
 def letterbox(frame: np.ndarray, size: int = 640, pad_value: int = 114):
     """ultralytics LetterBox for non-.pt backends: scale to fit, centre, pad to size x size with 114.
 
@@ -132,8 +154,9 @@ class Detector:
     def detect(self, frame: np.ndarray, flip_rgb: bool = True, masks: bool = True) -> Detections:
         """One HWC uint8 frame (any size) -> Detections in letterboxed 640x640 coordinates."""
         assert frame.ndim == 3 and frame.shape[-1] == 3 and frame.dtype == np.uint8, f"{frame.shape} {frame.dtype}"
-        img, _, _ = letterbox(frame, self.cfg.imgsz)
-        x = torch.from_numpy(img)[None].to(self.device)
+        # the raw frame goes to the GPU as it is; scale-to-fit + pad there (the host `letterbox` only supplies the geometry
+        # to callers that map coordinates back, e.g. CardSegmenter)
+        x, _, _ = letterbox_device(torch.from_numpy(np.ascontiguousarray(frame)).to(self.device), self.cfg.imgsz)
         out = self.forward(x, flip_rgb, self.cfg.max_det if masks else 0)
         n = int(out["n_det"][0].item())
         return Detections(

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mtgv_get_gemm_precision": (C.c_int, [C.POINTER(c_i32)]),
     "mtgv_bank_topk_packed": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_vp]),
     "mtgv_topk_merge_gathered": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "mtgv_letterbox_u8": (C.c_int, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "mtgv_profile_gemm": (C.c_int, [c_i32]),
     "mtgv_profile_gemm_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64)]),
     "mtgv_profile_gemm_bytes": (C.c_int, [C.POINTER(C.c_double)]),

@@ -13,7 +13,7 @@ from typing import Callable, Optional
 import torch
 
 from . import native
-from .crop import mask_quads_from_logits, select_cards, warp_quads
+from .crop import mask_quads_from_logits, select_cards, warp_quads, warp_workspace
 from .detector import Detector
 from .encoder import Encoder
 from .matcher import Matcher
@@ -104,6 +104,7 @@ class Pipeline:
         self.match_fn = match_fn or (lambda z, k: matcher.match(z, k))
         reps = (self.K + _PAD_BOXES.shape[0] - 1) // _PAD_BOXES.shape[0]
         self._pad = _PAD_BOXES.repeat(reps, 1)[: self.K].to(detector.device).contiguous()
+        self._warp_ws = None
 
     def _embed_match(self, frames_u8: torch.Tensor, det, lease=None):
         F, K = frames_u8.shape[0], self.K
@@ -119,7 +120,9 @@ class Pipeline:
             assert ml.shape[1] == K, f"mask rows {ml.shape[1]} != cards per frame {K}"
             quads, _ = mask_quads_from_logits(ml.view(F * K, *ml.shape[-2:]), sel)
         boxes = sel.view(F, K, 4)
-        crops = warp_quads(frames_u8, quads, frame_idx, self.encoder.cfg.image_hw, 0.05)
+        if self._warp_ws is None or self._warp_ws.numel() < 9 * F * K:
+            self._warp_ws = warp_workspace(F * K, frames_u8.device)  # once per pipeline (the largest batch seen so far)
+        crops = warp_quads(frames_u8, quads, frame_idx, self.encoder.cfg.image_hw, 0.05, self._warp_ws)
         if lease is not None:
             lease.done()  # the de-warp is the last reader of the frames
         z = self.encoder.encode(crops)

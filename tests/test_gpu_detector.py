@@ -154,6 +154,24 @@ def test_single_frame_api_and_letterbox(det_setup):
         det.detect(frame.astype(np.float32))
 
 
+@pytest.mark.parametrize("h,w", [(480, 640), (640, 640), (720, 1280), (300, 200), (33, 1000), (1080, 810)])
+def test_letterbox_kernel_bit_exact(h, w):
+    """scale-to-fit + centre + pad on the GPU (resize.hip letterbox_u8_kernel) against oracle/resize_ref.letterbox, every byte;
+    frames that already fit are copied exactly"""
+    from mtgv.detector import letterbox_device, letterbox_geometry
+    from oracle import resize_ref
+
+    frame = np.random.default_rng(h * 7 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got, r, (left, top) = letterbox_device(torch.from_numpy(frame).cuda(), 640)
+    ref = resize_ref.letterbox(frame, 640)
+    np.testing.assert_array_equal(got[0].cpu().numpy(), ref)
+    r2, nh, nw, top2, left2 = letterbox_geometry(h, w, 640)
+    assert (r, top, left) == (r2, top2, left2) and max(nh, nw) == 640
+    if (nh, nw) == (h, w):
+        np.testing.assert_array_equal(ref[top : top + nh, left : left + nw], frame)
+    assert (ref[:top] == 114).all() and (ref[:, :left] == 114).all()
+
+
 def test_detector_errors():
     from mtgv import spec
     from mtgv.detector import Detector

@@ -169,3 +169,23 @@ def test_byte_over_255_without_a_division_is_the_ieee_quotient():
         e = rnd32(Fraction(u) - Fraction(float(q)) * 255)
         q2 = rnd32(Fraction(float(e)) * Fraction(float(r)) + Fraction(float(q)))
         assert q2 == ref, u
+
+
+def test_letterbox_oracle_against_torch_interpolate():
+    """oracle/resize_ref.letterbox (the restatement the GPU kernel is checked against bit for bit) vs the host path it
+    replaces in `Detector.detect` (torch.nn.functional.interpolate, bilinear, align_corners=False): the same image up to one
+    grey level where the two summation orders round differently; pure padding for frames that already fit"""
+    import numpy as np
+
+    from mtgv.detector import letterbox
+    from oracle import resize_ref
+
+    for h, w in [(480, 640), (720, 1280), (300, 200), (1080, 810), (64, 64)]:
+        frame = np.random.default_rng(h + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = resize_ref.letterbox(frame, 640)
+        host, _, _ = letterbox(frame, 640)
+        d = np.abs(ref.astype(np.int32) - host.astype(np.int32))
+        assert d.max() <= 1, (h, w, d.max())
+        assert (d > 0).mean() < 0.02
+    frame = np.random.default_rng(0).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(resize_ref.letterbox(frame, 640)[80:560], frame)
