@@ -111,7 +111,7 @@ def parse():
                     "every rank: the sharded match is a collective): a freshly leased GPU can run its first few hundred milliseconds of "
                     "work below its sustained clocks (one box of round 3 timed a 0.2 s region 10 %% slower as the first process than "
                     "the same command a minute later)")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames in the bounded CPU-baseline sample")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="config.sustained_value: the same step loop run for at least this "
                     "long after the timed region (0: skip)")
     ap.add_argument("--no-h2d", action="store_true", help="skip config.with_h2d_value (frames arriving in pinned host memory)")

@@ -2,6 +2,7 @@
 // packed-FP32 VALU instructions; PK is always 0 - it kept a packed build of round 3 apart at link time).
 #pragma once
 #include "common.h"
+#include "dwconv7_ln_stream_kernel.h"
 #include "sp8.h"
 
 namespace mtgv {
@@ -287,6 +288,21 @@ static void dwconv7_ln_launch_t(const float* in, const float* w49, const float* 
   // widest strip (34.7 vs 38.6 us at 12 x 8 x 384, 20.3 vs 24.7 at 6 x 4 x 768).  MTGV_DW_ROWS=0: single-row kernel.
   const char* const rows_env = getenv("MTGV_DW_ROWS");  // read per call: tests compare the forms inside one process
   const bool rows_on = !(rows_env && atoi(rows_env) == 0);
+  // Row-streaming form (dwconv7_ln_stream_kernel.h: LDS-DMA row ring, one channel per thread, taps in registers;
+  // bit-identical): one block per image, so it needs a batch that fills the CUs; measured against the row-group form
+  // (tools/micro/dwconv_stream_probe.hip, profiles/r04_dwconv_stream_probe.txt) it wins where rows are long in pixels -
+  // 48 x 32 x 96: 121 vs 129 us, 24 x 16 x 192: 61 vs 66 - and ties or loses at 12 x 8 x 384 / 6 x 4 x 768.
+  // MTGV_DW_STREAM=0: off.
+  const char* const stream_env = getenv("MTGV_DW_STREAM");
+  if constexpr (PK == 0)
+  if (rows_on && !(stream_env && atoi(stream_env) == 0) && N >= 128) {
+#define DWSTREAM_GO(C_, G_)                                                                                                \
+  (out_fmt == 1 ? dwconv7_ln_stream_launch<C_, G_, 4, 3, true>(in, w49, bias, ln_w, ln_b, out, N, H, 1, eps, s)            \
+                : dwconv7_ln_stream_launch<C_, G_, 4, 3, false>(in, w49, bias, ln_w, ln_b, out, N, H, 1, eps, s))
+    if (C == 96 && W == 32) { DWSTREAM_GO(96, 8); return; }
+    if (C == 192 && W == 16) { DWSTREAM_GO(192, 4); return; }
+#undef DWSTREAM_GO
+  }
   if constexpr (PK == 0)  // the rows kernel is not keyed by PK: only the TU built without packed FP32 may instantiate it
   if (rows_on && W >= 4) {
     const int c4n_ = C / 4, S_ = 256 / c4n_;

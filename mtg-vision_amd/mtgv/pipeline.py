@@ -61,9 +61,9 @@ class HostFrames:
             ev.record(torch.cuda.current_stream(self.src.device))
             self.src.released[self.slot] = ev
 
-    def _issue(self):
+    def _issue(self, batch_index: int):
         j = self._issued % self.depth
-        h = self.host[self._issued % len(self.host)]
+        h = self.host[batch_index % len(self.host)]
         self._issued += 1
         with torch.cuda.stream(self.s_copy):
             if self.released[j] is not None:
@@ -73,14 +73,14 @@ class HostFrames:
         return HostFrames._Lease(self, j)
 
     def leases(self, n: int):
-        """n leases; copies run one to two batches ahead of their consumer.  Copy i + 1 is issued when lease i is handed
-        out (i >= 1): its buffer was last used by lease i - 2, whose done() the pipeline recorded one batch ago - so the
-        event the copy has to wait for always exists by then."""
-        ahead = [self._issue() for _ in range(min(n, self.depth - 1))]
+        """n leases of host batches 0, 1, ... (cyclically); copies run one to two batches ahead of their consumer.  Copy
+        i + 1 is issued when lease i is handed out (i >= 1): its buffer was last used by lease i - 2, whose done() the
+        pipeline recorded one batch ago - so the event the copy has to wait for always exists by then."""
+        ahead = [self._issue(b) for b in range(min(n, self.depth - 1))]
         issued = len(ahead)
         for i in range(n):
             if i > 0 and issued < n:
-                ahead.append(self._issue())
+                ahead.append(self._issue(issued))
                 issued += 1
             yield ahead.pop(0)
 

@@ -149,10 +149,12 @@ def test_block_vs_oracle(n, h, w, c, act):
     assert (got - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("n,h,w,c", [(3, 48, 32, 96), (2, 12, 8, 384), (2, 28, 28, 192), (2, 7, 7, 768), (1, 14, 14, 384), (1, 5, 9, 80), (2, 6, 4, 768)])
+@pytest.mark.parametrize("n,h,w,c", [(3, 48, 32, 96), (2, 12, 8, 384), (2, 28, 28, 192), (2, 7, 7, 768), (1, 14, 14, 384), (1, 5, 9, 80), (2, 6, 4, 768),
+                                     (130, 48, 32, 96), (129, 23, 16, 192), (128, 5, 32, 96)])
 def test_dwconv_ln_forms_are_bit_identical(n, h, w, c):
-    """the single-row form of dwconv7_ln (MTGV_DW_ROWS=0) and the row-group forms (three output rows per thread, ragged
-    last rows and strips included) give the same bits (whole block)"""
+    """the single-row form of dwconv7_ln (MTGV_DW_ROWS=0) and the default forms - row groups (three output rows per
+    thread, ragged last rows and strips included) and, from 128 images at 32 x 96 / 16 x 192 rows, the row-streaming
+    kernel (LDS-DMA row ring; ragged heights included) - give the same bits (whole block)"""
     import os
 
     nv = _lib()

@@ -148,3 +148,71 @@ def test_mask_segments_are_run_end_points_of_every_blob():
     q, ok = Q.mask_quad(two)
     host = np.asarray(InstanceSeg(points=both, label=0, conf=1.0).xyxyxyxy, np.float64)
     assert ok == 1 and np.abs(q - host).max() <= 1.5
+
+
+def _u_card(depth, notch_w, rot, W=100, H=140, S=200):
+    """a W x H card at (50, 30) of an S x S raster with a notch of notch_w x depth pixels cut into its bottom edge,
+    rotated by rot quarter turns"""
+    m = np.zeros((S, S), bool)
+    x0, y0 = 50, 30
+    m[y0 : y0 + H, x0 : x0 + W] = True
+    nx0 = x0 + (W - notch_w) // 2
+    m[y0 + H - depth : y0 + H, nx0 : nx0 + notch_w] = False
+    return np.rot90(m, rot).copy()
+
+
+def _top_edge(quad, v):
+    from oracle import quad_ref as Q
+
+    qcx, qcy = Q.hull_centroid(quad)
+    ex, ey = qcx + v[0] * 1e7, qcy + v[1] * 1e7
+    for i in range(1, 4):
+        c, d = quad[i], quad[(i + 1) % 4]
+        if Q._segments_touch(qcx, qcy, ex, ey, c[0], c[1], d[0], d[1]):
+            return i
+    return 0
+
+
+def _top_edges_hull_and_closing(m):
+    """the edge the ray test of od_export.py:76-88 picks with v from (a) the convex hull - quad_ref's substitution - and
+    (b) a raster closing with the reference's d = 0.2 sqrt(area) (od_export.py:58-61)"""
+    import math
+
+    from scipy import ndimage
+
+    from oracle import quad_ref as Q
+
+    ys, xmin, xmax, cnt, sumx = Q.row_extents(m)
+    hull = Q.hull_of_extents(ys, xmin, xmax)
+    a2 = sum(hull[i][0] * hull[(i + 1) % len(hull)][1] - hull[(i + 1) % len(hull)][0] * hull[i][1] for i in range(len(hull)))
+    if a2 < 0:
+        hull = [hull[0]] + hull[:0:-1]
+    quad = Q.approx_poly_n(hull, 4)
+    yy, xx = np.nonzero(m)
+    mc = np.array([xx.mean(), yy.mean()])
+    v_hull = mc - np.array(Q.hull_centroid(hull))
+    d = math.sqrt(m.sum()) * 0.2
+    r = int(round(d))
+    gy, gx = np.mgrid[-r : r + 1, -r : r + 1]
+    closed = ndimage.binary_closing(np.pad(m, r + 2), structure=(gy**2 + gx**2) <= d * d)[r + 2 : -r - 2, r + 2 : -r - 2]
+    cy, cx = np.nonzero(closed)
+    v_close = mc - np.array([cx.mean(), cy.mean()])
+    return _top_edge(quad, v_hull / np.linalg.norm(v_hull)), _top_edge(quad, v_close / np.linalg.norm(v_close)), 2 * d
+
+
+def test_hull_substitution_against_a_raster_closing_of_u_shaped_masks():
+    """quad_ref closes the U-shaped mask with its convex hull where the reference uses buffer(+d).buffer(-d)
+    (od_export.py:58-64), a morphological closing.  Against scipy's raster closing with the same d, in all four
+    orientations: same top edge for notches narrower than 2 d (the closing fills them) and for notches WIDER than 2 d
+    that end below the mask centroid; for notches both wider than 2 d and deeper than ~70 % of the card the closing
+    leaves the notch open and the reference's direction vector flips into it - the hull does not follow (documented in
+    oracle/quad_ref.py)."""
+    expected_top = {0: 0, 1: 3, 2: 2, 3: 1}  # the edge opposite the notch, per quarter turn
+    for rot in range(4):
+        for depth, notch_w in [(20, 30), (70, 30), (125, 30), (20, 55), (45, 75), (70, 55), (70, 75)]:
+            h, c, two_d = _top_edges_hull_and_closing(_u_card(depth, notch_w, rot))
+            assert (notch_w > two_d) == (notch_w >= 55)  # 55 and 75 px are wider than 2 d (27..47 px here)
+            assert h == c == expected_top[rot], (rot, depth, notch_w, h, c)
+        for depth, notch_w in [(100, 55), (125, 75)]:  # wide AND deep: the documented divergence
+            h, c, two_d = _top_edges_hull_and_closing(_u_card(depth, notch_w, rot))
+            assert notch_w > two_d and h == expected_top[rot] and c == (expected_top[rot] + 2) % 4, (rot, depth, notch_w, h, c)
