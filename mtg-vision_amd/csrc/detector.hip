@@ -290,6 +290,56 @@ __global__ __launch_bounds__(256) void maxpool5_sp8_kernel(const float* __restri
   o[0] = bh, o[1] = bl;
 }
 
+// SPPF's three chained 5x5 max pools (y1 = m(x), y2 = m(y1), y3 = m(y2)) in ONE launch: a block owns one 8-channel chunk
+// of one image, keeps the (hi, lo) pairs of all H x W pixels in LDS and runs the three rounds out of it - the three
+// separate launches were 25 us each for 6.5 MB of data (latency-bound: 25 dependent loads per thread).  Same comparison
+// (hi + lo), same scan order, same strict >: the pairs written are those of maxpool5_sp8_kernel, bit for bit.
+__global__ __launch_bounds__(256) void sppf_pools_sp8_kernel(float* __restrict__ buf, int c_total, int ch, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) char sp_sm[];
+  const int HW = H * W;
+  sp_h8* const a = reinterpret_cast<sp_h8*>(sp_sm);  // [HW][2]: hi piece, lo piece
+  sp_h8* const b = a + (size_t)HW * 2;
+  const int c8n = ch >> 3;
+  const long n = blockIdx.x / c8n;
+  const int c = (int)(blockIdx.x % c8n) * 8;
+  char* const img = reinterpret_cast<char*>(buf + n * (long)HW * c_total);
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const sp_h8* const src = reinterpret_cast<const sp_h8*>(img + ((long)p * c_total + c) * 4);
+    a[2 * p] = src[0], a[2 * p + 1] = src[1];
+  }
+  __syncthreads();
+  sp_h8 *in = a, *out = b;
+  for (int round = 1; round <= 3; ++round) {
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const int h = p / W, w = p - h * W;
+      float best[8];
+      sp_h8 bh, bl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) best[e] = -INFINITY, bh[e] = (_Float16)0.f, bl[e] = (_Float16)0.f;
+      for (int dh = -2; dh <= 2; ++dh) {
+        const int ih = h + dh;
+        if (ih < 0 || ih >= H) continue;
+        for (int dw = -2; dw <= 2; ++dw) {
+          const int iw = w + dw;
+          if (iw < 0 || iw >= W) continue;
+          const sp_h8 vh = in[2 * (ih * W + iw)], vl = in[2 * (ih * W + iw) + 1];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = (float)vh[e] + (float)vl[e];
+            if (v > best[e]) best[e] = v, bh[e] = vh[e], bl[e] = vl[e];
+          }
+        }
+      }
+      out[2 * p] = bh, out[2 * p + 1] = bl;
+      sp_h8* const dst = reinterpret_cast<sp_h8*>(img + ((long)p * c_total + round * ch + c) * 4);
+      dst[0] = bh, dst[1] = bl;
+    }
+    __syncthreads();
+    sp_h8* const t = in;
+    in = out, out = t;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // construction: expected ultralytics keys
 // ---------------------------------------------------------------------------
@@ -877,7 +927,13 @@ void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float
 void Detector::sppf(const std::string& P, const View& in, const View& spp, const View& out, int n, hipStream_t s) {
   const int ch = spp.ct / 4;
   conv(cw_.at(P + ".cv1"), in, spp.slice(0, ch), 1, ACT_SILU, nullptr, n, s);
-  if (!count_flops_)
+  const size_t pools_lds = (size_t)spp.H * spp.W * 64;  // two images of (hi, lo) pieces
+  const char* const pools_env = getenv("MTGV_SPPF_POOLS1");  // read per call (A/B in one process); 0: three launches
+  const bool pools1 = pools_env == nullptr || atoi(pools_env) != 0;
+  if (!count_flops_ && fmt_ == 1 && pools1 && pools_lds <= 64 * 1024 && ch % 8 == 0) {
+    hipLaunchKernelGGL(sppf_pools_sp8_kernel, dim3((unsigned)(n * (ch / 8))), dim3(256), pools_lds, s, spp.p, spp.ct, ch, spp.H, spp.W);
+    HIP_OK(hipGetLastError());
+  } else if (!count_flops_)
     for (int i = 0; i < 3; ++i) {
       if (fmt_ == 1) {
         const long total = (long)n * spp.H * spp.W * (ch / 8);

@@ -86,7 +86,8 @@ def test_detector_batch32_equals_single_frames():
 @pytest.mark.parametrize("arch", ["yolov8n-seg", "yolo11n-seg"])
 def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
     """the forward's internal fork-join (prototype branch and P3 / P4 heads on library-owned streams beside the neck,
-    detector.hip) and the ConvTranspose as ONE scattered launch give the same bits as the serial, four-launch schedule -
+    detector.hip), the ConvTranspose as ONE scattered launch and SPPF's three max pools as ONE launch give the same bits as
+    the serial schedule with their separate launches -
     raw predictions, prototypes, kept indices, boxes and mask logits - at batch 32, repeatedly (a race between the
     branches would show as run-to-run differences)"""
     import os
@@ -101,6 +102,7 @@ def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
 
     def run(fork, up1):
         os.environ["MTGV_DET_FORK"], os.environ["MTGV_PROTO_UP1"] = fork, up1
+        os.environ["MTGV_SPPF_POOLS1"] = up1  # SPPF's three max pools as one launch, switched together with the upsample form
         try:
             out = {k: (v.clone() if v is not None else None) for k, v in det.forward(frames, True, 8).items()}
             pred, protos = det.raw_outputs(32)
@@ -108,7 +110,7 @@ def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
             torch.cuda.synchronize()
             return out
         finally:
-            os.environ.pop("MTGV_DET_FORK", None), os.environ.pop("MTGV_PROTO_UP1", None)
+            os.environ.pop("MTGV_DET_FORK", None), os.environ.pop("MTGV_PROTO_UP1", None), os.environ.pop("MTGV_SPPF_POOLS1", None)
 
     base = run("0", "0")
     assert (base["n_det"] > 0).any()

@@ -24,6 +24,6 @@ def timeit(fn, warm=5, it=30):
 
 for rep in range(2):
     for fork, up1 in (("0", "0"), ("0", "1"), ("1", "0"), ("1", "1")):
-        os.environ["MTGV_DET_FORK"], os.environ["MTGV_PROTO_UP1"] = fork, up1
+        os.environ["MTGV_DET_FORK"], os.environ["MTGV_PROTO_UP1"], os.environ["MTGV_SPPF_POOLS1"] = fork, up1, up1
         ms = timeit(lambda: det.forward(fr, True, 8))
         print(f"{arch} b=32 fork={fork} up1={up1}: {ms:.3f} ms  {32 / ms * 1e3:.0f} frames/s", flush=True)
