@@ -182,14 +182,6 @@ bool sp_enabled() {
 }
 
 bool is_conv(const GemmArgs& a) { return !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.stride_w <= 1 && a.pad == 0); }
-
-// A mode 7 (per-image multipliers fetched to registers): whole 32-k stages, 16-byte aligned multiplier rows.
-// MTGV_SP_ASCR=0 keeps to A mode 3 (multipliers staged through LDS); read per call so that tools can compare.
-bool ascr_ok(const GemmArgs& a) {
-  const char* e = getenv("MTGV_SP_ASCR");
-  if (e != nullptr && atoi(e) == 0) return false;
-  return a.a_scale != nullptr && a.a_fmt == 0 && a.K % 32 == 0 && ((uintptr_t)a.a_scale & 15) == 0 && a.a_mul == 1.0f;
-}
 }  // namespace
 
 bool window_conv_on() {
@@ -266,17 +258,12 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
     const int c = atoi(e);
     if (c >= 0 && c < kNumCfg) best = c;
   }
-  if (const char* e = getenv("MTGV_SP_PW2_CFG")) {  // tuning aid: tile configuration of the GRN-scaled (pwconv2) launches only
-    const int c = atoi(e);
-    if (a.a_scale != nullptr && !sp8_in && c >= 0 && c < kNumCfg && kCfg[c].eff > 0.0 && !(c == 1 && !ascr_ok(a))) best = c;
-  }
   if (best < 0) {
     for (int c = 0; c < kNumCfg; ++c) {
       const SpCfg& k = kCfg[c];
       if (k.eff <= 0.0) continue;  // not part of the search
-      // the 1 KB-per-stage multiplier image of the f32-by-DMA A path (A mode 3) does not fit beside the 128 x 192 ring
-      // twice per CU; with the multipliers in registers (A mode 7) it does
-      if (c == 1 && !sp8_in && a.a_scale != nullptr && !ascr_ok(a)) continue;
+      // the 1 KB-per-stage multiplier image of the f32-by-DMA A path does not fit beside the 128 x 192 ring twice per CU
+      if (c == 1 && !sp8_in && a.a_scale != nullptr) continue;
       const long tiles = (long)ceil_div(a.M, k.bm()) * ceil_div(a.N, k.bn());
       // two blocks per CU: a "round" is up to 512 tiles, each CU working on two at half speed
       const double rounds = (double)((tiles + 511) / 512);
@@ -327,7 +314,7 @@ double gemm_sp_fill_bytes(const GemmArgs& a, const SpPlan& pl) {
   double a_tile = (double)k.bm() * a.K * 4.0;  // dense rows, or one gather per tap
   if (a.a_fmt == 1 && is_conv(a) && window_conv_fits(a, pl))
     a_tile = (double)((k.bm() + 2 * a.Wd + 2 + 7) & ~7) * 128.0 * (a.Cin / 32);
-  if (a.a_scale != nullptr && !ascr_ok(a)) a_tile += (double)(a.K / 32) * 1024.0;  // (A mode 3's multiplier image)
+  if (a.a_scale != nullptr) a_tile += (double)(a.K / 32) * 1024.0;
   return tiles * (a_tile + b_tile);
 }
 
@@ -433,7 +420,6 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   if (amode == 2 && window_conv_fits(a, pl)) amode = 5;
   if (amode == 1 && g.a_mul == 1.0f && ((uintptr_t)g.A & 15) == 0) {
     if (g.a_scale == nullptr) amode = 4;
-    else if (ascr_ok(a)) amode = 7;
     else if (((uintptr_t)g.a_scale & 15) == 0 && (kCfg[pl.cfg].bm() - 1) / g.hw + 2 <= 8) amode = 3;
   }
   if (stamps_on() && gemm_profile_enabled()) {

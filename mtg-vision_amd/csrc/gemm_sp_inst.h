@@ -105,13 +105,6 @@ void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_
   } else if (amode == 3) {
     if (g.act == ACT_NONE) sp_pick<3, ACT_NONE, 2>(g, epi, s);
     else sp_pick<3, -1>(g, epi, s);
-  } else if (amode == 7) {
-#if SP_NST == 2
-    if (g.act == ACT_NONE) sp_pick<7, ACT_NONE, 2>(g, epi, s);
-    else sp_pick<7, -1>(g, epi, s);
-#else
-    MTGV_CHECK(false, ERR_RUNTIME, "gemm_sp: the register-multiplier path has no deep-ring instance");
-#endif
   } else if (amode == 4) {
     if (g.act == ACT_NONE) sp_pick<4, ACT_NONE, 0, 2>(g, epi, s);
     else sp_pick<4, -1>(g, epi, s);

@@ -17,12 +17,6 @@
 //   A, AMODE 3 / 4       f32 rows by LDS-DMA; the wave that feeds a fragment to the MFMAs multiplies it by the per-image
 //                        multipliers (AMODE 3: GRN apply, convnextv2.py:171-174; one extra 1 KB DMA piece per stage holds
 //                        [8 images][32 k]) and splits it into hi / lo on the spot.
-//   A, AMODE 7           as AMODE 3, but the multipliers never touch LDS: a lane's rows are fixed for the tile, so it
-//                        fetches its own 16 multipliers per stage (image of its row, its half of each k16 step) into
-//                        registers one stage ahead (4 x 16 B through the vector L1: the same few lines for all lanes of
-//                        an image).  Per k16 step that is two ds_read_b128 per row block less - the AMODE 3 wave reads
-//                        1.1 KB of LDS per MFMA, above the 1 KB / MFMA the CU's 128 B/clk LDS delivers at full matrix
-//                        rate - and no 1 KB scale image per stage, so the 128 x 192 tile fits twice per CU.  K % 32 == 0.
 //   A, AMODE 6 (HI16)    A and B are plain fp16 rows (the hi halves only, 2 bytes per element): a stage is 64 k, one MFMA
 //                        per k16 step.  The approximate first pass of the bank match (match.hip); K % 64 == 0.
 //   A, AMODE 1 (REG)     f32 rows: global -> VGPR (issued before the stage's MFMAs) -> optional per-image multiplier
@@ -102,8 +96,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   constexpr int RB = 64 * KS, RPP = 1024 / RB, SPR = RB / 16;
   constexpr bool AWIN = AMODE == 5;  // 3x3 / stride 1 / pad 1 conv: the tile's input window is staged once per 32 channels
   constexpr bool ADMA = AMODE != 1 && !AWIN;
-  constexpr bool AF32 = AMODE == 3 || AMODE == 4 || AMODE == 7;  // f32 rows by DMA, split into hi / lo when a fragment is read
-  constexpr bool ASCR = AMODE == 7;                               // per-image multipliers in registers
+  constexpr bool AF32 = AMODE == 3 || AMODE == 4;  // f32 rows by DMA, split into hi / lo when a fragment is read
   constexpr bool HI16 = AMODE == 6;                // fp16 rows on both sides: 2 bytes per element, 64 k per 128-byte stage row
   constexpr int EB = HI16 ? 2 : 4;                 // bytes per operand element in memory
   static_assert(!HI16 || (KS == 2 && EPI == 16), "fp16 rows: 128-byte stage rows, top-k epilogue");
@@ -338,7 +331,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
       if (s0 < nk) issue(s0, s0);
     loadA(0);
   }
-  static_assert(!(AMODE == 7) || NST == 2, "the register multipliers are fetched exactly one stage ahead");
   int wy[TM], wx[TM];  // AWIN: (y, x) of this lane's output pixels
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -377,32 +369,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
       sc_off[i] = (unsigned)(SA + SB + ((int)fdiv((uint32_t)m, g.d_hw) - img0) * 128 + h * 32);
     }
   }
-
-  // AMODE 7: this lane's multipliers of the stage in flight (scn) and of the stage being consumed (scc):
-  // [row block][k16 step][4-float half]
-  const float* scp[TM];
-  sp_f4 scn[TM][2][2], scc[TM][2][2];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    scp[i] = nullptr;
-    if constexpr (ASCR) {
-      int m = m0 + wm * TM * 32 + i * 32 + r;
-      m = m < g.M ? m : g.M - 1;
-      scp[i] = g.a_scale + (long)fdiv((uint32_t)m, g.d_hw) * g.K + h * 8;
-    }
-  }
-  auto load_scale = [&](int t) {
-    if constexpr (ASCR) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const sp_f4* const q = reinterpret_cast<const sp_f4*>(scp[i] + t * 32 + ks * 16);
-          scn[i][ks][0] = q[0], scn[i][ks][1] = q[1];
-        }
-    }
-  };
-  load_scale(0);
 
   // Epilogue geometry (see the epilogue): on the read-back side a lane owns columns nw0 + 32 j + 4 slot + 0..3 of
   // every row it touches; their scales and biases are fetched now, under the main loop.
@@ -537,16 +503,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
       wait_stage(t + NST - 1 > nk);
       __builtin_amdgcn_s_barrier();
       if (g.stamps != nullptr && t == 0) st1 = (long)__builtin_amdgcn_s_memtime();
-      if constexpr (ASCR) {  // (vmcnt(0) above covered the multipliers of stage t, requested during stage t - 1)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) scc[i][ks][0] = scn[i][ks][0], scc[i][ks][1] = scn[i][ks][1];
-      }
       if (t + NST - 1 < nk) {
         issue(t + NST - 1, nbuf);
         loadA(t + 1);
-        load_scale(t + 1);
       }
       if (wave_active && HI16) {  // four k16 steps per stage, one product each
         const char* const sb = ring + buf * STG;
@@ -585,10 +544,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
                 xa[ks][i][0] = xa[ks][i][0] * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
                 xa[ks][i][1] = xa[ks][i][1] * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
               }
-              if constexpr (ASCR) {
-                xa[ks][i][0] = xa[ks][i][0] * scc[i][ks][0];
-                xa[ks][i][1] = xa[ks][i][1] * scc[i][ks][1];
-              }
             }
   #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -620,7 +575,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
           }
           // issue order: every LDS read, the first step's conversion, then the first step's MFMAs one by one, each
           // followed by a share of the second step's conversion
-          constexpr int CV = ((AMODE == 3 || ASCR) ? 8 : 0) + 16;  // vector instructions per fragment: scale, split
+          constexpr int CV = (AMODE == 3 ? 8 : 0) + 16;  // vector instructions per fragment: scale, split
           __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM * (AMODE == 3 ? 4 : 2) + 2 * TN), 0);  // DS read
           __builtin_amdgcn_sched_group_barrier(0x002, CV * TM, 0);                                     // VALU
   #pragma unroll
@@ -644,10 +599,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
               if constexpr (AMODE == 3) {
                 x0 = x0 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
                 x1 = x1 * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
-              }
-              if constexpr (ASCR) {
-                x0 = x0 * scc[i][ks][0];
-                x1 = x1 * scc[i][ks][1];
               }
               sp8_split8_mix(x0, x1, ah[i], al[i]);  // (same values as sp8_split8, 8 vector instructions fewer per 8 elements)
             } else {
