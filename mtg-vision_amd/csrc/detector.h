@@ -39,10 +39,6 @@ class Detector {
   void finalize();
   void forward(const uint8_t* frames, int n, int flip, int* n_det, float* boxes, float* conf, int* cls, int* keep_idx,
                float* mask_logits, int mask_rows, hipStream_t s);
-  // frames [n0, n0 + n) of the batch (n0_ set by the caller): every buffer of the arena is [frame][...], so a part is the
-  // same launches on offset pointers
-  void forward_part(const uint8_t* frames, int n, int flip, int* n_det, float* boxes, float* conf, int* cls, int* keep_idx,
-                    float* mask_logits, int mask_rows, hipStream_t s);
   void raw(int n, float* pred, float* protos, hipStream_t s);
   double flops_per_frame() const { return flops_; }
   const mtgv_detector_cfg& cfg() const { return cfg_; }
@@ -122,15 +118,10 @@ class Detector {
   size_t nms_ws_bytes_ = 0;
   int last_n_ = 0;
   int fmt_ = 0;  // activation format of the forward in progress (0 f32, 1 SP8)
-  // Streams the forward owns.  Per batch part (NPART: a batch of >= 16 frames runs as two halves, the second on its own
-  // stream - the late, small layers of one half then share the GPU with the early, chip-filling layers of the other):
-  // index 0 the part's own stream (part 0 uses the caller's), 1: prototype branch, 2: P3 head, 3: P4 head.
-  static constexpr int NPART = 2, NSIDE = 4;
-  hipStream_t side_[NPART][NSIDE] = {};
-  hipEvent_t ev_fork_[NPART][NSIDE] = {}, ev_join_[NPART][NSIDE] = {};
-  bool side_busy_[NPART][NSIDE] = {};  // forked in the forward in progress and not joined yet
-  int part_ = 0;                       // batch part being issued
-  int n0_ = 0;                         // its first frame
+  static constexpr int NSIDE = 3;  // 0: prototype branch, 1: P3 head, 2: P4 head
+  hipStream_t side_[NSIDE] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork_[NSIDE] = {nullptr, nullptr, nullptr}, ev_join_[NSIDE] = {nullptr, nullptr, nullptr};
+  bool side_busy_[NSIDE] = {false, false, false};  // forked in the forward in progress and not joined yet
 };
 
 }  // namespace mtgv

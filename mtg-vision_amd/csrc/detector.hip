@@ -436,12 +436,11 @@ Detector::~Detector() {
     (void)hipFree(p);
   }
   if (nms_ws_) (void)hipFree(nms_ws_);
-  for (int p = 0; p < NPART; ++p)
-    for (int i = 0; i < NSIDE; ++i) {
-      if (side_[p][i]) (void)hipStreamDestroy(side_[p][i]);
-      if (ev_fork_[p][i]) (void)hipEventDestroy(ev_fork_[p][i]);
-      if (ev_join_[p][i]) (void)hipEventDestroy(ev_join_[p][i]);
-    }
+  for (int i = 0; i < NSIDE; ++i) {
+    if (side_[i]) (void)hipStreamDestroy(side_[i]);
+    if (ev_fork_[i]) (void)hipEventDestroy(ev_fork_[i]);
+    if (ev_join_[i]) (void)hipEventDestroy(ev_join_[i]);
+  }
 }
 
 bool Detector::fork_enabled() const {
@@ -451,24 +450,22 @@ bool Detector::fork_enabled() const {
 
 hipStream_t Detector::fork_after(hipStream_t s, int i) {
   if (!fork_enabled()) return s;
-  const int p = part_;
-  if (side_[p][i] == nullptr) {
-    HIP_OK(hipStreamCreateWithFlags(&side_[p][i], hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&ev_fork_[p][i], hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&ev_join_[p][i], hipEventDisableTiming));
+  if (side_[i] == nullptr) {
+    HIP_OK(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&ev_fork_[i], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
   }
-  HIP_OK(hipEventRecord(ev_fork_[p][i], s));
-  HIP_OK(hipStreamWaitEvent(side_[p][i], ev_fork_[p][i], 0));
-  side_busy_[p][i] = true;
-  return side_[p][i];
+  HIP_OK(hipEventRecord(ev_fork_[i], s));
+  HIP_OK(hipStreamWaitEvent(side_[i], ev_fork_[i], 0));
+  side_busy_[i] = true;
+  return side_[i];
 }
 
 void Detector::join_into(hipStream_t s, int i) {
-  const int p = part_;
-  if (!side_busy_[p][i]) return;
-  HIP_OK(hipEventRecord(ev_join_[p][i], side_[p][i]));
-  HIP_OK(hipStreamWaitEvent(s, ev_join_[p][i], 0));
-  side_busy_[p][i] = false;
+  if (!side_busy_[i]) return;
+  HIP_OK(hipEventRecord(ev_join_[i], side_[i]));
+  HIP_OK(hipStreamWaitEvent(s, ev_join_[i], 0));
+  side_busy_[i] = false;
 }
 
 void Detector::set_param(const char* key, const float* host, int64_t numel) {
@@ -550,7 +547,6 @@ View Detector::take(int n, int h, int w, int c) {
 View Detector::view(const std::string& k) const {
   View v = v_.at(k);
   v.fmt = (k == "x0" || k == "protos") ? 0 : fmt_;
-  v.p += (size_t)n0_ * v.H * v.W * v.ct;  // the batch part in progress starts at frame n0_
   return v;
 }
 
@@ -874,32 +870,25 @@ void Detector::head_tail(int n, int* n_det, float* boxes, float* conf, int* cls,
                          hipStream_t s) {
   const int S = cfg_.imgsz;
   const long tot = (long)n * na_;
-  // this part's slices of the per-frame buffers
-  const float* const rh0 = rawhead_[0] + (size_t)n0_ * (S / 8) * (S / 8) * RAW_CT;
-  const float* const rh1 = rawhead_[1] + (size_t)n0_ * (S / 16) * (S / 16) * RAW_CT;
-  const float* const rh2 = rawhead_[2] + (size_t)n0_ * (S / 32) * (S / 32) * RAW_CT;
-  float* const pred = pred_ + (size_t)n0_ * no() * na_;
-  float* const coef = coef_ + (size_t)n0_ * cfg_.max_det * nm_;
-  const size_t ws1 = nms_workspace_bytes(1, na_);
-  int* const nws = reinterpret_cast<int*>(reinterpret_cast<char*>(nms_ws_) + (size_t)n0_ * ws1);
-  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rh0, rh1, rh2, pred, n, cfg_.nc, nm_, S, na_);
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rawhead_[0], rawhead_[1], rawhead_[2],
+                     pred_, n, cfg_.nc, nm_, S, na_);
   HIP_OK(hipGetLastError());
-  nms_launch(pred, n, cfg_.nc, nm_, na_, cfg_.conf, cfg_.iou, cfg_.max_det, 7680.0f, n_det, boxes, conf, cls, keep_idx, coef, nws,
-             (size_t)n * ws1, s);
-  join_into(s, 1);  // the prototype branch ran beside the heads, decode and NMS (one workgroup per frame: 32 of 256 CUs)
+  nms_launch(pred_, n, cfg_.nc, nm_, na_, cfg_.conf, cfg_.iou, cfg_.max_det, 7680.0f, n_det, boxes, conf, cls, keep_idx, coef_,
+             nms_ws_, nms_ws_bytes_, s);
+  join_into(s, 0);  // the prototype branch ran beside the heads, decode and NMS (one workgroup per frame: 32 of 256 CUs)
   if (mask_logits != nullptr) {
     // masks = coeffs @ protos^T per image, cropped to the box (process_mask / crop_mask)
     const View pr = view("protos");
     const int npx = pr.H * pr.W;
     if (nm_ == 32 && mask_rows <= 16 && !count_flops_) {  // a handful of masks per frame: one pass over the prototypes
-      hipLaunchKernelGGL(mask_logits_kernel, dim3((unsigned)((npx + 255) / 256), (unsigned)n), dim3(256), 0, s, coef, pr.p, n_det, boxes,
+      hipLaunchKernelGGL(mask_logits_kernel, dim3((unsigned)((npx + 255) / 256), (unsigned)n), dim3(256), 0, s, coef_, pr.p, n_det, boxes,
                          mask_logits, npx, pr.W, mask_rows, cfg_.max_det, (float)pr.W / (float)S);
       HIP_OK(hipGetLastError());
       return;
     }
     // the batched GEMM writes only the rows of kept detections: the rest is cleared first
     HIP_OK(hipMemsetAsync(mask_logits, 0, (size_t)n * mask_rows * npx * sizeof(float), s));
-    GemmArgs g = linear_args(coef, nm_, pr.p, nullptr, mask_logits, npx, mask_rows, npx, nm_, ACT_NONE);
+    GemmArgs g = linear_args(coef_, nm_, pr.p, nullptr, mask_logits, npx, mask_rows, npx, nm_, ACT_NONE);
     g.batch = n;
     g.strideA = (long)cfg_.max_det * nm_;
     g.strideW = (long)npx * nm_;
@@ -924,44 +913,6 @@ void Detector::forward(const uint8_t* frames, int n, int flip, int* n_det, float
   // f16x3 on the LDS-DMA kernel: every intermediate activation is kept in SP8; the frame, the raw head rows and the
   // prototypes (decode / mask inputs) stay f32
   fmt_ = (!count_flops_ && gemm_sp_active()) ? 1 : 0;
-  // Two half batches, the second on its own stream (library kernels only, joined before control of `s` returns): a
-  // forward is a chain of ~80 launches whose late layers (P4 / P5: 100 - 400 tiles for 256 CUs) cannot fill the GPU;
-  // the other half's early layers can.  A frame's results do not depend on its batch (no cross-row reduction), so the
-  // outputs are those of the single pass, bit for bit.  MTGV_DET_SPLIT=1: one pass.
-  int parts = 1;
-  if (!count_flops_ && fork_enabled() && n >= 16) {
-    const char* e = getenv("MTGV_DET_SPLIT");  // read per call
-    parts = e != nullptr ? atoi(e) : NPART;
-    parts = parts < 1 ? 1 : (parts > NPART ? NPART : parts);
-  }
-  const size_t fpx = (size_t)cfg_.imgsz * cfg_.imgsz * 3;
-  const int md = cfg_.max_det;
-  const size_t mpx = (size_t)(cfg_.imgsz / 4) * (cfg_.imgsz / 4);
-  hipStream_t sps[NPART];
-  sps[0] = s;
-  for (int p = 1; p < parts; ++p) {  // the other parts' streams start after what is on s NOW, not after part 0's launches
-    part_ = p;
-    sps[p] = fork_after(s, 0);
-  }
-  for (int p = 0; p < parts; ++p) {
-    const int a = (int)((long)n * p / parts), b = (int)((long)n * (p + 1) / parts);
-    part_ = p, n0_ = a;
-    hipStream_t sp = sps[p];
-    forward_part(frames ? frames + a * fpx : nullptr, b - a, flip, n_det ? n_det + a : nullptr, boxes ? boxes + (size_t)a * md * 4 : nullptr,
-                 conf ? conf + (size_t)a * md : nullptr, cls ? cls + (size_t)a * md : nullptr, keep_idx ? keep_idx + (size_t)a * md : nullptr,
-                 mask_logits ? mask_logits + (size_t)a * mask_rows * mpx : nullptr, mask_rows, sp);
-  }
-  for (int p = 1; p < parts; ++p) {
-    part_ = p;
-    join_into(s, 0);
-  }
-  part_ = 0, n0_ = 0;
-  if (count_flops_) return;
-  last_n_ = n;
-}
-
-void Detector::forward_part(const uint8_t* frames, int n, int flip, int* n_det, float* boxes, float* conf, int* cls, int* keep_idx,
-                            float* mask_logits, int mask_rows, hipStream_t s) {
   if (v11()) {
     forward_v11(frames, n, flip, s);
   } else {
@@ -969,6 +920,7 @@ void Detector::forward_part(const uint8_t* frames, int n, int flip, int* n_det, 
   }
   if (count_flops_) return;
   head_tail(n, n_det, boxes, conf, cls, keep_idx, mask_logits, mask_rows, s);
+  last_n_ = n;
 }
 
 // SPPF: cv1, three chained 5x5 max pools, cv2 over the concat
@@ -1020,15 +972,15 @@ void Detector::forward_v8(const uint8_t* frames, int n, int flip, hipStream_t s)
   c2f(15, cat14, V("p3"), n, s);
   // P3 exists: the prototype branch (0.5 ms of chip-filling launches) and the P3 head leave the caller's stream; the
   // rest of the neck - 100..400-tile launches that cannot fill 256 CUs on their own - runs beside them
-  proto(head_, V("p3"), n, fork_after(s, 1));
-  head_level_v8(0, n, fork_after(s, 2));
+  proto(head_, V("p3"), n, fork_after(s, 0));
+  head_level_v8(0, n, fork_after(s, 1));
   conv(cw_.at("model.16"), V("p3"), cat17.slice(0, c64), 2, ACT_SILU, nullptr, n, s);
   c2f(18, cat17, V("p4"), n, s);
-  head_level_v8(1, n, fork_after(s, 3));
+  head_level_v8(1, n, fork_after(s, 2));
   conv(cw_.at("model.19"), V("p4"), cat20.slice(0, c128), 2, ACT_SILU, nullptr, n, s);
   c2f(21, cat20, V("p5"), n, s);
   head_level_v8(2, n, s);
-  join_into(s, 2), join_into(s, 3);  // (the prototype branch is joined in head_tail, after decode + NMS)
+  join_into(s, 1), join_into(s, 2);  // (the prototype branch is joined in head_tail, after decode + NMS)
 }
 
 // Segment head of level l (P3 / P4 / P5): the three branches' first 3x3 convs as one launch, then per branch 3x3 -> 1x1
@@ -1041,7 +993,7 @@ void Detector::head_level_v8(int l, int n, hipStream_t s) {
   conv(head_cls2_[l], t1.slice(64, 64), t2.slice(64, 64), 1, ACT_SILU, nullptr, n, s);
   conv(head_coef2_[l], t1.slice(128, 32), t2.slice(128, 32), 1, ACT_SILU, nullptr, n, s);
   View rh;
-  rh.p = rawhead_[l] + (size_t)n0_ * f.H * f.W * RAW_CT, rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
+  rh.p = rawhead_[l], rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
   conv(head_box3_[l], t2.slice(0, 64), rh.slice(0, 64), 1, ACT_NONE, nullptr, n, s);
   conv(head_cls3_[l], t2.slice(64, 64), rh.slice(RAW_CLS, cfg_.nc), 1, ACT_NONE, nullptr, n, s);
   conv(head_coef3_[l], t2.slice(128, 32), rh.slice(RAW_COEF, nm_), 1, ACT_NONE, nullptr, n, s);

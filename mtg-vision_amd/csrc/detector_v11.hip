@@ -422,15 +422,15 @@ void Detector::forward_v11(const uint8_t* frames, int n, int flip, hipStream_t s
   if (!count_flops_) upsample2x_launch(n13.p, n13.ct, n13.co, cat15.p, cat15.ct, 0, n, n13.H, n13.W, c128, s);
   c3k2(16, cat15, V("p3"), n, s);
   // the same fork-join as forward_v8: prototype branch and P3 / P4 heads beside the rest of the neck
-  proto(head_, V("p3"), n, fork_after(s, 1));
-  head_level_v11(0, n, fork_after(s, 2));
+  proto(head_, V("p3"), n, fork_after(s, 0));
+  head_level_v11(0, n, fork_after(s, 1));
   conv(cw_.at("model.17"), V("p3"), cat18.slice(0, c64), 2, ACT_SILU, nullptr, n, s);
   c3k2(19, cat18, V("p4"), n, s);
-  head_level_v11(1, n, fork_after(s, 3));
+  head_level_v11(1, n, fork_after(s, 2));
   conv(cw_.at("model.20"), V("p4"), cat21.slice(0, c128), 2, ACT_SILU, nullptr, n, s);
   c3k2(22, cat21, V("p5"), n, s);
   head_level_v11(2, n, s);
-  join_into(s, 2), join_into(s, 3);
+  join_into(s, 1), join_into(s, 2);
 }
 
 // Segment head of level l: box + coefficient branches (first 3x3 convs merged), class branch of depthwise + pointwise pairs
@@ -439,7 +439,7 @@ void Detector::head_level_v11(int l, int n, hipStream_t s) {
   const std::string ls = std::to_string(l);
   const View f = view(feats[l]), t1 = view("t1_" + ls), t2 = view("t2_" + ls);
   View rh;
-  rh.p = rawhead_[l] + (size_t)n0_ * f.H * f.W * RAW_CT, rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
+  rh.p = rawhead_[l], rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
   conv(head_bc_[l], f, t1, 1, ACT_SILU, nullptr, n, s);
   conv(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, ACT_SILU, nullptr, n, s);
   conv(head_coef2_[l], t1.slice(64, 32), t2.slice(64, 32), 1, ACT_SILU, nullptr, n, s);

@@ -89,7 +89,7 @@ def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
     detector.hip), the ConvTranspose as ONE scattered launch and SPPF's three max pools as ONE launch give the same bits as
     the serial schedule with their separate launches -
     raw predictions, prototypes, kept indices, boxes and mask logits - at batch 32, repeatedly (a race between the
-    branches would show as run-to-run differences); so does the batch run as two halves on two streams (MTGV_DET_SPLIT)"""
+    branches would show as run-to-run differences)"""
     import os
 
     from mtgv import spec
@@ -100,8 +100,8 @@ def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
     g = torch.Generator(device="cuda").manual_seed(5)
     frames = torch.randint(0, 256, (32, 640, 640, 3), generator=g, device="cuda", dtype=torch.uint8)
 
-    def run(fork, up1, split="2"):
-        os.environ["MTGV_DET_FORK"], os.environ["MTGV_PROTO_UP1"], os.environ["MTGV_DET_SPLIT"] = fork, up1, split
+    def run(fork, up1):
+        os.environ["MTGV_DET_FORK"], os.environ["MTGV_PROTO_UP1"] = fork, up1
         os.environ["MTGV_SPPF_POOLS1"] = up1  # SPPF's three max pools as one launch, switched together with the upsample form
         try:
             out = {k: (v.clone() if v is not None else None) for k, v in det.forward(frames, True, 8).items()}
@@ -110,15 +110,15 @@ def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
             torch.cuda.synchronize()
             return out
         finally:
-            os.environ.pop("MTGV_DET_FORK", None), os.environ.pop("MTGV_PROTO_UP1", None), os.environ.pop("MTGV_SPPF_POOLS1", None), os.environ.pop("MTGV_DET_SPLIT", None)
+            os.environ.pop("MTGV_DET_FORK", None), os.environ.pop("MTGV_PROTO_UP1", None), os.environ.pop("MTGV_SPPF_POOLS1", None)
 
     base = run("0", "0")
     assert (base["n_det"] > 0).any()
     for rep in range(3):
-        for fork, up1, split in (("1", "1", "2"), ("1", "0", "1"), ("0", "1", "1"), ("1", "1", "1")):
-            got = run(fork, up1, split)
+        for fork, up1 in (("1", "1"), ("1", "0"), ("0", "1")):
+            got = run(fork, up1)
             for k in ("pred", "protos", "n_det", "keep_idx", "boxes", "conf", "cls", "mask_logits"):
-                assert torch.equal(got[k], base[k]), (k, fork, up1, split, rep)
+                assert torch.equal(got[k], base[k]), (k, fork, up1, rep)
 
 
 @pytest.mark.parametrize("quad_source", ["mask", "box"])
