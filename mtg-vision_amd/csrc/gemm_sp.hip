@@ -154,13 +154,17 @@ void gemm_sp_launch_cfg2(const SpDev& g, int amode, hipStream_t s);
 void gemm_sp_launch_cfg3(const SpDev& g, int amode, hipStream_t s);
 void gemm_sp_launch_cfg4(const SpDev& g, int amode, hipStream_t s);
 void gemm_sp_launch_cfg5(const SpDev& g, int amode, hipStream_t s);
+void gemm_sp_launch_cfg6(const SpDev& g, int amode, hipStream_t s);
 
 namespace {
 struct SpCfg {
   int wm, wn, tm, tn;
   double eff;  // relative efficiency of the tile's main loop (fitted to tools/gemm_sp_sweep.py)
+  int ks = 2;  // k16 steps per stage
   int bm() const { return 32 * tm * wm; }
   int bn() const { return 32 * tn * wn; }
+  int rb() const { return 64 * ks; }          // bytes per staged row
+  int kps() const { return 16 * ks; }         // k per stage
 };
 const SpCfg kCfg[] = {
     {2, 2, 2, 2, 0.93},  // 128 x 128
@@ -169,6 +173,7 @@ const SpCfg kCfg[] = {
     {4, 1, 1, 2, 0.80},  // 128 x  64
     {4, 1, 1, 1, 0.62},  // 128 x  32
     {4, 2, 1, 3, 0.00},  // 128 x 192 on eight waves (swapped in for configuration 1 below; not part of the search)
+    {4, 1, 1, 1, 0.00, 1},  // 128 x 32 in 16-k stages: window convs with 16-channel slices only (chosen below, not searched)
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -191,13 +196,17 @@ bool window_conv_on() {
 
 // 3x3 / stride 1 / pad 1 convs whose channels come in slices of 32: stage the tile's input window once per slice
 // instead of gathering every tap from L2 (1.65 - 2.2x fewer LDS fill bytes), while two blocks still fit a CU
+static size_t window_bytes(const SpCfg& k, int Wd) {
+  const int rpp = 1024 / k.rb();
+  return (size_t)((k.bm() + 2 * Wd + 2 + rpp - 1) / rpp * rpp) * k.rb();
+}
+
 bool window_conv_fits(const GemmArgs& a, const SpPlan& pl) {
-  if (!(window_conv_on() && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.stride_w <= 0 && a.Cin % 32 == 0 &&
+  const SpCfg& k = kCfg[pl.cfg];
+  if (!(window_conv_on() && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.stride_w <= 0 && a.Cin % k.kps() == 0 &&
         a.OH == a.H && a.OW == a.Wd))
     return false;
-  const SpCfg& k = kCfg[pl.cfg];
-  const size_t lds = (size_t)((k.bm() + 2 * a.Wd + 2 + 7) & ~7) * 128 + (size_t)2 * k.bn() * 128;
-  return lds <= 80 * 1024;
+  return window_bytes(k, a.Wd) + (size_t)2 * k.bn() * k.rb() <= 80 * 1024;
 }
 
 bool topk_sp_on() {
@@ -256,7 +265,7 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
   double best_cost = 0;
   if (const char* e = getenv("MTGV_SP_CFG")) {
     const int c = atoi(e);
-    if (c >= 0 && c < kNumCfg) best = c;
+    if (c >= 0 && c < kNumCfg && kCfg[c].ks == 2) best = c;
   }
   if (best < 0) {
     for (int c = 0; c < kNumCfg; ++c) {
@@ -271,6 +280,12 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
       const double cost = per_cu / k.eff;
       if (best < 0 || cost < best_cost) best = c, best_cost = cost;
     }
+  }
+  {  // 3x3 / stride-1 convs with 16-channel slices (Cin % 32 != 0): the window conv in 16-k stages instead of nine tap gathers
+    static const bool on6 = [] { const char* e = getenv("MTGV_SP_CFG6"); return e == nullptr || atoi(e) != 0; }();
+    SpPlan p6;
+    p6.cfg = 6;
+    if (on6 && getenv("MTGV_SP_CFG") == nullptr && conv && sp8_in && a.Cin % 32 != 0 && a.N <= 32 && window_conv_fits(a, p6)) best = 6;
   }
   {  // eight-wave twin of the 128 x 192 tile (four waves per SIMD) for pwconv1-shaped launches: SP8 rows in, activation
      // + GRN sums out; measured -3..-4 % on the stage 2-3 layers, nothing on the others (MTGV_SP_CFG8=0: off)
@@ -312,8 +327,7 @@ double gemm_sp_fill_bytes(const GemmArgs& a, const SpPlan& pl) {
   const double tiles = (double)pl.tiles_m * pl.tiles_n;
   const double b_tile = (double)k.bn() * a.K * 4.0;
   double a_tile = (double)k.bm() * a.K * 4.0;  // dense rows, or one gather per tap
-  if (a.a_fmt == 1 && is_conv(a) && window_conv_fits(a, pl))
-    a_tile = (double)((k.bm() + 2 * a.Wd + 2 + 7) & ~7) * 128.0 * (a.Cin / 32);
+  if (a.a_fmt == 1 && is_conv(a) && window_conv_fits(a, pl)) a_tile = (double)window_bytes(k, a.Wd) * (a.Cin / k.kps());
   if (a.a_scale != nullptr) a_tile += (double)(a.K / 32) * 1024.0;
   return tiles * (a_tile + b_tile);
 }
@@ -437,6 +451,7 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
     case 3: gemm_sp_launch_cfg3(g, amode, s); break;
     case 4: gemm_sp_launch_cfg4(g, amode, s); break;
     case 5: gemm_sp_launch_cfg5(g, amode, s); break;
+    case 6: gemm_sp_launch_cfg6(g, amode, s); break;
     default: MTGV_CHECK(false, ERR_INVALID, "gemm_sp: bad cfg %d", pl.cfg);
   }
   HIP_OK(hipGetLastError());

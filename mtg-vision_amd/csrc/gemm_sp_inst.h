@@ -8,7 +8,10 @@
 namespace mtgv {
 
 namespace {
-constexpr int SP_KS = 2;
+#ifndef SP_KS_VALUE
+#define SP_KS_VALUE 2
+#endif
+constexpr int SP_KS = SP_KS_VALUE;  // k16 steps per stage: 2 (32-k stages); 1 in the 16-channel window-conv configuration
 #ifndef SP_NST
 #define SP_NST 2
 #endif
@@ -18,8 +21,9 @@ void sp_launch_nst(const SpDev& g, hipStream_t s) {
   constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN;
   constexpr size_t ring = (size_t)NST * ((AMODE == 5 ? BN : BM + BN) * 64 * SP_KS + (AMODE == 3 ? 1024 : 0));
   size_t lds = ring;
-  if (AMODE == 5) {  // window of BM + 2 W + 2 pixels x 128 B in front of the weight ring; the epilogue stages 32 rows per wave
-    const size_t win = (size_t)((BM + 2 * g.Wd + 2 + 7) & ~7) * 128;
+  if (AMODE == 5) {  // window of BM + 2 W + 2 pixels x (64 KS) B in front of the weight ring; the epilogue stages 32 rows per wave
+    constexpr int RB = 64 * SP_KS, RPP = 1024 / RB;
+    const size_t win = (size_t)((BM + 2 * g.Wd + 2 + RPP - 1) / RPP * RPP) * RB;
     const size_t stage = (size_t)SP_WM * SP_WN * 32 * 128 * SP_TN;
     lds = win + ring > stage ? win + ring : stage;
   }
@@ -39,10 +43,10 @@ void sp_launch_one(const SpDev& g, hipStream_t s) {
     // window conv: a four-deep weight ring (three taps ahead) for launches of at most one round of tiles - there a tile's
     // latency is the launch's duration (12800-row layers -15..-25 %); with several rounds the blocks per CU matter more
     // (the deeper ring costs one: 204800 x 32 layers +12 %) and the two-deep ring stays
-    constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN;
-    const size_t win = (size_t)((BM + 2 * g.Wd + 2 + 7) & ~7) * 128;
+    constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN, RB = 64 * SP_KS, RPP = 1024 / RB;
+    const size_t win = (size_t)((BM + 2 * g.Wd + 2 + RPP - 1) / RPP * RPP) * RB;
     static const bool deep_on = [] { const char* e = getenv("MTGV_SP_WINRING"); return e == nullptr || atoi(e) != 0; }();
-    if (deep_on && (long)g.tiles_m * g.tiles_n <= 512 && win + (size_t)4 * BN * 128 <= 80 * 1024) {
+    if (deep_on && (long)g.tiles_m * g.tiles_n <= 512 && win + (size_t)4 * BN * RB <= 80 * 1024) {
       sp_launch_nst<AMODE, ACT, EPI, 4>(g, s);
       return;
     }
@@ -87,6 +91,22 @@ void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_
 #endif
   }
   const int epi = sp_epi_of(g);
+#if SP_KS_VALUE != 2
+  // the 16-k configuration exists for the conv paths only (window conv, and the tap gather it falls back to)
+  MTGV_CHECK(amode == 5 || amode == 2, ERR_RUNTIME, "gemm_sp: configuration %d runs convolutions only (A mode %d)", SP_CFG_ID, amode);
+  if (amode == 5) {
+    switch (g.act) {
+      case ACT_SILU: sp_pick<5, ACT_SILU, 1, 5>(g, epi, s); break;
+      default: sp_pick<5, -1>(g, epi, s); break;
+    }
+  } else {
+    switch (g.act) {
+      case ACT_SILU: sp_pick<2, ACT_SILU, 1, 5>(g, epi, s); break;
+      default: sp_pick<2, -1>(g, epi, s); break;
+    }
+  }
+  return;
+#else
   if (amode == 0) {
     switch (g.act) {
       case ACT_NONE: sp_pick<0, ACT_NONE, 0, 1>(g, epi, s); break;
@@ -124,6 +144,7 @@ void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_
       default: sp_pick<2, -1>(g, epi, s); break;
     }
   }
+#endif
 }
 
 }  // namespace mtgv

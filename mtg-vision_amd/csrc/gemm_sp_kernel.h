@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   constexpr int EB = HI16 ? 2 : 4;                 // bytes per operand element in memory
   static_assert(!HI16 || (KS == 2 && EPI == 16), "fp16 rows: 128-byte stage rows, top-k epilogue");
   constexpr int SA = AWIN ? 0 : BM * RB, SB = BN * RB, SSC = AMODE == 3 ? 1024 : 0, STG = SA + SB + SSC;
-  static_assert(!AWIN || KS == 2, "window conv: 32-channel stages");
+  // (window conv: 32-channel stages with KS == 2, 16-channel stages - the detector's 16-channel bottlenecks - with KS == 1)
   static_assert(AMODE != 3 || KS == 2, "the scale image is one DMA piece: 8 images x 32 k");
   constexpr int PA = ADMA ? BM / RPP : 0, PB = BN / RPP, NP = PA + PB;
   constexpr int PPW = (NP + NW - 1) / NW;
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
     sc_tailz = ktail && ((nk - 1) * 2 * KS + ((lane & 7) >> 1)) >= kchunks;
   }
   // AWIN: [window: win_px pixels x 128 B][weight ring]; otherwise the ring starts at the base
-  const int win_px = AWIN ? ((BM + 2 * g.Wd + 2 + 7) & ~7) : 0;
-  char* const ring = smem + (AWIN ? win_px * 128 : 0);
+  const int win_px = AWIN ? ((BM + 2 * g.Wd + 2 + RPP - 1) / RPP * RPP) : 0;  // whole 1 KB pieces
+  char* const ring = smem + (AWIN ? win_px * RB : 0);
   // one piece the general way: per-lane 64-bit source (conv gather, K tail -> zero page)
   auto issue_piece = [&](int u, int t, int buf) {
     const int p = wave + NW * u;
@@ -304,14 +304,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   };
 
   // AWIN: window pixel w holds input pixel m0 - Wd - 1 + w (output and input share the linear (img, y, x) index:
-  // stride 1, pad 1); pieces of 8 pixels x 128 B, 16-byte slots swizzled by the pixel like the rows of a dense A stage
+  // stride 1, pad 1); pieces of RPP pixels x RB bytes (8 x 128 B, or 16 x 64 B for 16-channel slices), 16-byte slots
+  // swizzled by the pixel like the rows of a dense A stage
   auto issue_window = [&](int cc) {
     if constexpr (AWIN) {
-      for (int pw = wave; pw < (win_px >> 3); pw += NW) {
-        const int w = pw * 8 + (lane >> 3);
+      for (int pw = wave; pw < win_px / RPP; pw += NW) {
+        const int w = pw * RPP + lane / SPR;
         const long gp = (long)m0 - g.Wd - 1 + w;
-        const int slot = (lane & 7) ^ ((w >> 1) & 7);
-        const char* sp = (gp >= 0 && gp < (long)g.M) ? g.A + gp * g.a_rowb + g.a_offb + cc * 128 + slot * 16 : g.zero;
+        const int slot = (lane % SPR) ^ (KS == 2 ? (w >> 1) & 7 : (w >> 2) & 3);
+        const char* sp = (gp >= 0 && gp < (long)g.M) ? g.A + gp * g.a_rowb + g.a_offb + cc * RB + slot * 16 : g.zero;
         __builtin_amdgcn_global_load_lds((sp_gptr)sp, (sp_lptr)(smem + pw * 1024), 16, 0, 0);
       }
     }
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   // The first stages are requested now, before the rest of the set-up (accumulators, fragment offsets, epilogue
   // constants): their latency runs under it.
   if constexpr (AWIN) {
-    // weights of the first NST - 1 (slice, tap) steps: step tau = 9 cc + tap reads K stage tap * (Cin / 32) + cc
-    const int ncc0 = g.Cin >> 5;
+    // weights of the first NST - 1 (slice, tap) steps: step tau = 9 cc + tap reads K stage tap * (Cin / KPS) + cc
+    const int ncc0 = g.Cin / (16 * KS);
 #pragma unroll
     for (int s0 = 0; s0 < NST - 1; ++s0)
       if (s0 < 9 * ncc0) issue((s0 % 9) * ncc0 + s0 / 9, s0);
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
     // per 32-channel slice: stage the window once, then 9 taps x 2 k-steps out of it while the taps' weight stages
     // ring through NST buffers (NST - 1 taps ahead: a tap's 6 TN MFMAs are far shorter than a DMA round trip, so the
     // two-deep ring stalled on every tap).  Accumulation order: channel slice outer, tap inner.
-    const int ncc = g.Cin >> 5;
+    const int ncc = g.Cin / (16 * KS);
     const int ntau = 9 * ncc;
     const char* const win = smem;
     int buf = 0, nbuf = NST - 1;
@@ -457,8 +458,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const int w = wm * TM * 32 + i * 32 + r + shift;
-            w_off[i] = (unsigned)w * 128u;
-            w_sw[i] = (unsigned)(w >> 1) & 7u;
+            w_off[i] = (unsigned)w * (unsigned)RB;
+            w_sw[i] = KS == 2 ? (unsigned)(w >> 1) & 7u : (unsigned)(w >> 2) & 3u;
             w_ok[i] = (unsigned)(wy[i] + dy) < (unsigned)g.H && (unsigned)(wx[i] + dx) < (unsigned)g.Wd;
           }
 #pragma unroll
