@@ -11,5 +11,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $ROOT/bench.py --steps 2 --warmup 1 \
     --no-cpu-baseline --no-roofline --no-overlap --no-h2d --sustained-seconds 0 --settle-steps 0 --precision $PREC > $OUT/$C.log 2>&1
 done
-python3 $ROOT/tools/pmc_traffic.py $OUT 6 $PREC  # 6 steps: (1 warm-up + 2 timed) before the (empty) settle phase and again after it > $OUT/traffic.json
+# 6 steps: (1 warm-up + 2 timed) before the (empty) settle phase and again after it
+python3 $ROOT/tools/pmc_traffic.py $OUT 6 $PREC > $OUT/traffic.json
 tail -3 $OUT/traffic.json
