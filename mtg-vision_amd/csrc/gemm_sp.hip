@@ -282,7 +282,7 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
     }
   }
   {  // 3x3 / stride-1 convs with 16-channel slices (Cin % 32 != 0): the window conv in 16-k stages instead of nine tap gathers
-    static const bool on6 = [] { const char* e = getenv("MTGV_SP_CFG6"); return e == nullptr || atoi(e) != 0; }();
+    static const bool on6 = [] { const char* e = getenv("MTGV_SP_WIN16"); return e == nullptr || atoi(e) != 0; }();
     SpPlan p6;
     p6.cfg = 6;
     if (on6 && getenv("MTGV_SP_CFG") == nullptr && conv && sp8_in && a.Cin % 32 != 0 && a.N <= 32 && window_conv_fits(a, p6)) best = 6;
