@@ -59,7 +59,7 @@ def group_launches(recs, nprof, precision):
         d = out.setdefault(g, {"launches": 0, "ms": 0.0, "flop": 0.0, "issued": 0.0, "bytes": 0.0, "fill": 0.0})
         d["launches"] += 1
         d["ms"] += float(r["ms"])
-        fl = 2.0 * int(r["M"]) * int(r["N"]) * int(r["K"]) * int(r["batch"])
+        fl = 2.0 * int(r["M"]) * int(r["N"]) * int(r["K"]) * int(r["batch"]) + float(r.get("xflops", 0) or 0)  # (+ a chained second layer)
         d["flop"] += fl
         # MFMA FLOPs issued per algorithmic FLOP: 3 for the split products, 1 for f32 operands and for the fp16 first
         # pass of the two-pass bank match (sp = 3), 6 for the fused MLP's output pass (sp = 2 with a GRN-scaled A:

@@ -58,7 +58,11 @@ class Detector {
   ConvW concat_out(const std::vector<ConvW>& parts);                // stack along cout
   float* upload(const std::vector<float>& v, int row_k = 0);  // row_k > 0: a GEMM B operand with rows of row_k floats
   void conv(const ConvW& w, const View& in, const View& out, int stride, int act, const View* res, int n, hipStream_t s);
-  void c2f(int idx, const View& in, const View& out, int n, hipStream_t s);
+  // Conv(w1, SiLU) followed by the 1x1 conv w2 (act2) with w1's output consumed on chip (gemm_sp_kernel.h, EPI 32): `mid` is
+  // where w1's output would go in two launches (used when the pair cannot be chained: f32 mode, flop counting, shapes)
+  void conv_pair(const ConvW& w1, const View& in, const View& mid, int stride, const ConvW& w2, const View& out2, int act2, int n,
+                 hipStream_t s);
+  void c2f(int idx, const View& in, const View& out, int n, hipStream_t s, const ConvW* pre = nullptr, const View* pre_in = nullptr);
   // YOLO11 modules
   ConvW fold_dw(const std::string& prefix);                         // depthwise 3x3 Conv+BN -> weight [9][c], bias [c]
   void dwconv(const ConvW& w, const View& in, const View& out, int act, const float* add, int g_size, int g_stride, int n,

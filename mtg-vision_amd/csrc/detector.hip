@@ -746,14 +746,41 @@ void Detector::conv(const ConvW& w, const View& in, const View& out, int stride,
   gemm_launch(g, gemm_plan(g.M, g.N, g.K, act != ACT_NONE), s);
 }
 
+void Detector::conv_pair(const ConvW& w1, const View& in, const View& mid, int stride, const ConvW& w2, const View& out2, int act2, int n,
+                         hipStream_t s) {
+  MTGV_CHECK(in.C == w1.cin && mid.C == w1.cout && w2.cin == w1.cout && w2.k == 1 && out2.C == w2.cout, ERR_RUNTIME,
+             "detector: conv pair channel mismatch (%d->%d, %d->%d)", w1.cin, w1.cout, w2.cin, w2.cout);
+  const char* const ce = getenv("MTGV_DET_CHAIN");  // read per call (A/B in one process); 0: two launches
+  if (!count_flops_ && fmt_ == 1 && !(ce != nullptr && atoi(ce) == 0)) {
+    GemmArgs g;
+    g.A = in.p, g.W = w1.w, g.bias = w1.b, g.Out = nullptr;
+    g.M = n * mid.H * mid.W, g.N = w1.cout, g.K = w1.k * w1.k * w1.cin;
+    g.H = in.H, g.Wd = in.W, g.c_total = in.ct, g.c_off = in.co, g.Cin = in.C;
+    g.KH = w1.k, g.KW = w1.k, g.stride = stride, g.pad = w1.k / 2;
+    g.OH = mid.H, g.OW = mid.W, g.OH2 = mid.H, g.OW2 = mid.W;
+    g.ldo = mid.ct, g.o_off = mid.co;
+    g.act = ACT_SILU;
+    g.a_fmt = in.fmt, g.out_fmt = mid.fmt;
+    g.W2 = w2.w, g.bias2 = w2.b, g.Out2 = out2.p, g.N2 = w2.cout, g.ldo2 = out2.ct, g.o_off2 = out2.co, g.out_fmt2 = out2.fmt, g.act2 = act2;
+    if (gemm_sp_chain_ok(g)) {
+      gemm_launch(g, gemm_plan(g.M, g.N, g.K, true), s);
+      return;
+    }
+  }
+  conv(w1, in, mid, stride, ACT_SILU, nullptr, n, s);
+  conv(w2, mid, out2, 1, act2, nullptr, n, s);
+}
+
 // C2f: cv1 -> 2 chunks; n bottlenecks (3x3,3x3, +shortcut) each appended; cv2 over the concat
-void Detector::c2f(int idx, const View& in, const View& out, int n, hipStream_t s) {
+void Detector::c2f(int idx, const View& in, const View& out, int n, hipStream_t s, const ConvW* pre, const View* pre_in) {
   const C2fInfo& ci = c2f_.at(idx);
   const int ch = ci.cout / 2;
   const std::string P = "model." + std::to_string(idx);
   const View cat = view("cat" + std::to_string(idx));
   const View tmp = view("tmp" + std::to_string(idx));
-  conv(cw_.at(P + ".cv1"), in, cat.slice(0, 2 * ch), 1, ACT_SILU, nullptr, n, s);
+  // pre: the stride-2 Conv in front of this block, whose only consumer is cv1 - the pair runs as one launch where it can
+  if (pre != nullptr) conv_pair(*pre, *pre_in, in, 2, cw_.at(P + ".cv1"), cat.slice(0, 2 * ch), ACT_SILU, n, s);
+  else conv(cw_.at(P + ".cv1"), in, cat.slice(0, 2 * ch), 1, ACT_SILU, nullptr, n, s);
   for (int j = 0; j < ci.n; ++j) {
     const View src = cat.slice((1 + j) * ch, ch);
     const View dst = cat.slice((2 + j) * ch, ch);
@@ -824,8 +851,7 @@ void Detector::proto(const std::string& H, const View& p3, int n, hipStream_t s)
         gemm_launch(g, gemm_plan(g.M, g.N, g.K), s);
     }
   }
-  conv(cw_.at(H + ".proto.cv2"), view("pr2"), view("pr3"), 1, ACT_SILU, nullptr, n, s);
-  conv(cw_.at(H + ".proto.cv3"), view("pr3"), view("protos"), 1, ACT_SILU, nullptr, n, s);
+  conv_pair(cw_.at(H + ".proto.cv2"), view("pr2"), view("pr3"), 1, cw_.at(H + ".proto.cv3"), view("protos"), ACT_SILU, n, s);
 }
 
 // Mask logits of a few detections per frame (process_mask + crop_mask behind od_export.py:152): out[z][m][px] =
@@ -951,11 +977,13 @@ void Detector::forward_v8(const uint8_t* frames, int n, int flip, hipStream_t s)
   const int c64 = chn(256), c128 = chn(512), c256 = chn(1024);
   auto V = [&](const char* k) -> View { return view(k); };
   conv0(frames, n, flip, s);
-  conv(cw_.at("model.1"), V("l0"), V("l1"), 2, ACT_SILU, nullptr, n, s);
-  c2f(2, V("l1"), V("l2"), n, s);
-  conv(cw_.at("model.3"), V("l2"), V("l3"), 2, ACT_SILU, nullptr, n, s);
-  const View n4 = V("cat14").slice(c128, c64);      // node 4 output lives in concat 14 = [up(12), 4]
-  c2f(4, V("l3"), n4, n, s);
+  {
+    const View l0 = V("l0"), l2 = V("l2");
+    c2f(2, V("l1"), l2, n, s, &cw_.at("model.1"), &l0);  // model.1 (3x3 s2) + cv1 in one launch: l1 is never stored
+    const View n4 = V("cat14").slice(c128, c64);       // node 4 output lives in concat 14 = [up(12), 4]
+    c2f(4, V("l3"), n4, n, s, &cw_.at("model.3"), &l2);
+  }
+  const View n4 = V("cat14").slice(c128, c64);
   conv(cw_.at("model.5"), n4, V("l5"), 2, ACT_SILU, nullptr, n, s);
   const View n6 = V("cat11").slice(c256, c128);     // concat 11 = [up(9), 6]
   c2f(6, V("l5"), n6, n, s);
@@ -989,14 +1017,13 @@ void Detector::head_level_v8(int l, int n, hipStream_t s) {
   const std::string ls = std::to_string(l);
   const View f = view(feats[l]), t1 = view("t1_" + ls), t2 = view("t2_" + ls);
   conv(head_first_[l], f, t1, 1, ACT_SILU, nullptr, n, s);
-  conv(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, ACT_SILU, nullptr, n, s);
-  conv(head_cls2_[l], t1.slice(64, 64), t2.slice(64, 64), 1, ACT_SILU, nullptr, n, s);
-  conv(head_coef2_[l], t1.slice(128, 32), t2.slice(128, 32), 1, ACT_SILU, nullptr, n, s);
   View rh;
   rh.p = rawhead_[l], rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
-  conv(head_box3_[l], t2.slice(0, 64), rh.slice(0, 64), 1, ACT_NONE, nullptr, n, s);
+  // box and coefficient branches: the 3x3 and the final 1x1 as one launch each (the class branch's 3 outputs are no column quad)
+  conv_pair(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, head_box3_[l], rh.slice(0, 64), ACT_NONE, n, s);
+  conv(head_cls2_[l], t1.slice(64, 64), t2.slice(64, 64), 1, ACT_SILU, nullptr, n, s);
+  conv_pair(head_coef2_[l], t1.slice(128, 32), t2.slice(128, 32), 1, head_coef3_[l], rh.slice(RAW_COEF, nm_), ACT_NONE, n, s);
   conv(head_cls3_[l], t2.slice(64, 64), rh.slice(RAW_CLS, cfg_.nc), 1, ACT_NONE, nullptr, n, s);
-  conv(head_coef3_[l], t2.slice(128, 32), rh.slice(RAW_COEF, nm_), 1, ACT_NONE, nullptr, n, s);
 }
 
 void Detector::raw(int n, float* pred, float* protos, hipStream_t s) {

@@ -441,10 +441,8 @@ void Detector::head_level_v11(int l, int n, hipStream_t s) {
   View rh;
   rh.p = rawhead_[l], rh.H = f.H, rh.W = f.W, rh.ct = RAW_CT, rh.co = 0, rh.C = RAW_CT;
   conv(head_bc_[l], f, t1, 1, ACT_SILU, nullptr, n, s);
-  conv(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, ACT_SILU, nullptr, n, s);
-  conv(head_coef2_[l], t1.slice(64, 32), t2.slice(64, 32), 1, ACT_SILU, nullptr, n, s);
-  conv(head_box3_[l], t2.slice(0, 64), rh.slice(0, 64), 1, ACT_NONE, nullptr, n, s);
-  conv(head_coef3_[l], t2.slice(64, 32), rh.slice(RAW_COEF, nm_), 1, ACT_NONE, nullptr, n, s);
+  conv_pair(head_box2_[l], t1.slice(0, 64), t2.slice(0, 64), 1, head_box3_[l], rh.slice(0, 64), ACT_NONE, n, s);
+  conv_pair(head_coef2_[l], t1.slice(64, 32), t2.slice(64, 32), 1, head_coef3_[l], rh.slice(RAW_COEF, nm_), ACT_NONE, n, s);
   // class branch: (depthwise 3x3, 1x1) twice, then the plain 1x1
   const View da = view("dwa_" + ls), db = view("dwb_" + ls), dc = view("dwc_" + ls), dd = view("dwd_" + ls);
   dwconv(cls_dw1_[l], f, da, ACT_SILU, nullptr, 0, 0, n, s);

@@ -47,6 +47,12 @@ struct GemmArgs {
   // (oy, ox) = (q / os, q % os), channel n % os_nq - a whole ConvTranspose2d(k = s = os) as ONE launch that reads its
   // input once (W rows ordered (kh, kw, cout); bias repeated per group).  os_nq % 8 == 0.
   int os_nq = 0;
+  // Chained 1x1 (LDS-DMA kernel only, gemm_sp_chain_ok): a second layer W2 [N2][N] (+ bias2, act2) applied to this launch's
+  // activated output rows inside the epilogue; only Out2 is stored (Out may be null).  N in {32, 64, 96}, N2 % 32 == 0, N2 <= N.
+  const float* W2 = nullptr;
+  const float* bias2 = nullptr;
+  float* Out2 = nullptr;
+  int N2 = 0, ldo2 = 0, o_off2 = 0, out_fmt2 = 0, act2 = ACT_NONE;
   int ldr = 0;
   int act = ACT_NONE;
 

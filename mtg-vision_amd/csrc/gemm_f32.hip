@@ -38,7 +38,7 @@ struct GemmProf {
   double flops = 0;
   double bytes = 0;  // compulsory HBM bytes: every operand element read once, every output written once
   long launches = 0;
-  struct Rec { int M, N, K, KH, stride, batch, act, apro, grn, topk, sp; double bytes, fill; };
+  struct Rec { int M, N, K, KH, stride, batch, act, apro, grn, topk, sp; double bytes, fill, xflops; };
   std::vector<Rec> recs;
 } g_prof;
 }  // namespace
@@ -56,16 +56,16 @@ void gemm_profile_enable(bool on) {
 void gemm_profile_dump(const char* path) {
   FILE* f = fopen(path, "w");
   MTGV_CHECK(f != nullptr, ERR_RUNTIME, "cannot open %s", path);
-  fprintf(f, "idx,M,N,K,KH,stride,batch,act,apro,grn,topk,tm,tn,bk,ms,tflops,bytes,sp,fill\n");
+  fprintf(f, "idx,M,N,K,KH,stride,batch,act,apro,grn,topk,tm,tn,bk,ms,tflops,bytes,sp,fill,xflops\n");
   for (size_t i = 0; i + 1 < g_prof.used && i / 2 < g_prof.recs.size(); i += 2) {
     HIP_OK(hipEventSynchronize(g_prof.ev[i + 1]));
     float t = 0.f;
     HIP_OK(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
     const auto& r = g_prof.recs[i / 2];
     const GemmPlan pl = r.topk ? GemmPlan{1, 2, 16, 0, 0} : gemm_plan(r.M, r.N, r.K, r.act != 0, r.apro != 0);
-    const double fl = 2.0 * r.M * r.N * r.K * r.batch;
-    fprintf(f, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f,%.0f,%d,%.0f\n", i / 2, r.M, r.N, r.K, r.KH, r.stride, r.batch, r.act,
-            r.apro, r.grn, r.topk, pl.tm, pl.tn, pl.bk, t, fl / (t * 1e-3) / 1e12, r.bytes, r.sp, r.fill);
+    const double fl = 2.0 * r.M * r.N * r.K * r.batch + r.xflops;  // xflops: a second layer chained into the launch
+    fprintf(f, "%zu,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.2f,%.0f,%d,%.0f,%.0f\n", i / 2, r.M, r.N, r.K, r.KH, r.stride, r.batch, r.act,
+            r.apro, r.grn, r.topk, pl.tm, pl.tn, pl.bk, t, fl / (t * 1e-3) / 1e12, r.bytes, r.sp, r.fill, r.xflops);
   }
   fclose(f);
   gemm_sp_stamps_dump((std::string(path) + ".stamps").c_str());
@@ -96,18 +96,21 @@ static void prof_begin(const GemmArgs& a, hipStream_t s, int sp, double fill, do
     g_prof.ev.push_back(e);
   }
   HIP_OK(hipEventRecord(g_prof.ev[g_prof.used], s));
-  g_prof.flops += 2.0 * (double)a.M * a.N * a.K * a.batch;
+  const double xfl = a.W2 != nullptr ? 2.0 * (double)a.M * a.N2 * a.N : 0.0;
+  g_prof.flops += 2.0 * (double)a.M * a.N * a.K * a.batch + xfl;
   {
     const bool conv = !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.stride_w <= 1 && a.pad == 0);
     const double a_el = conv ? (double)(a.M / (a.OH * a.OW)) * a.H * a.Wd * a.Cin : (double)a.M * a.K;
     const double w_el = (double)a.N * a.K;
-    const double o_el = a.topk > 0 ? (double)a.M * ceil_div(a.N, 64) * a.topk * 2 : (double)a.M * a.N;
+    // (a chained launch stores only its second layer's output and reads the second weight matrix besides)
+    const double o_el = a.topk > 0 ? (double)a.M * ceil_div(a.N, 64) * a.topk * 2
+                                   : (a.W2 != nullptr ? (double)a.M * a.N2 + (double)a.N2 * a.N : (double)a.M * a.N);
     const double r_el = a.res != nullptr ? (double)a.M * a.N : 0.0;
     double by = 4.0 * ((a.strideA != 0 || a.batch == 1 ? a.batch : 1) * a_el + (a.strideW != 0 || a.batch == 1 ? a.batch : 1) * w_el +
                        a.batch * (o_el + r_el));
     if (bytes_override >= 0.0) by = bytes_override;
     g_prof.bytes += by;
-    g_prof.recs.push_back({a.M, a.N, a.K, a.KH, a.stride, a.batch, a.act, a.a_scale != nullptr, a.grn_part != nullptr, a.topk, sp, by, fill});
+    g_prof.recs.push_back({a.M, a.N, a.K, a.KH, a.stride, a.batch, a.act, a.a_scale != nullptr, a.grn_part != nullptr, a.topk, sp, by, fill, xfl});
   }
   g_prof.launches += 1;
 }
@@ -367,6 +370,7 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
   }
 
   MTGV_CHECK(a.os_nq == 0, ERR_INVALID, "gemm: the grouped scatter epilogue (os_nq) exists on the LDS-DMA kernel only");
+  MTGV_CHECK(a.W2 == nullptr, ERR_INVALID, "gemm: the chained 1x1 exists on the LDS-DMA kernel only");
   GemmDev g;
   g.a = a;
   if (gemm_precision() == GEMM_PREC_F16X3 && g.a.W_split == nullptr && a.strideW == 0)

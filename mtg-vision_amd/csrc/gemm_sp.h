@@ -30,6 +30,8 @@ SpPlan gemm_sp_plan(const GemmArgs& a);
 // choosing their output format)
 bool gemm_sp_takes_sp8(const float* W, int M, int N, int K, int lda, int c_off);
 void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s);
+// can the launch described by `a` (W2 / bias2 / Out2 / N2 ... set) run with its second layer chained into the epilogue?
+bool gemm_sp_chain_ok(const GemmArgs& a);
 bool gemm_sp_topk_layout(const GemmArgs& a, int* slots, int* cols);  // candidate groups of a top-k launch the SP kernel takes
 double gemm_sp_fill_bytes(const GemmArgs& a, const SpPlan& pl);  // LDS fill bytes of the launch (profiling aid)
 void gemm_sp_stamps_dump(const char* path);  // tuning aid, see gemm_sp.hip

@@ -222,8 +222,34 @@ bool gemm_sp_takes_sp8(const float* W, int M, int N, int K, int lda, int c_off) 
   return sp8_lookup(W, K, nullptr, nullptr);
 }
 
+// chained 1x1: SP8 conv / dense input, SiLU between the layers, the whole output row in one tile of a one-wave-column
+// configuration (N = 32 / 64 / 96 -> configurations 4 / 3 / 2), plain epilogue otherwise
+static int chain_cfg(const GemmArgs& a) {
+  static const bool on = [] { const char* e = getenv("MTGV_SP_CHAIN"); return e == nullptr || atoi(e) != 0; }();
+  if (!on || a.W2 == nullptr || a.Out2 == nullptr) return -1;
+  if (!(gemm_sp_active() && a.a_fmt == 1 && a.act == ACT_SILU && a.res == nullptr && a.grn_part == nullptr && a.topk == 0 && a.batch == 1 &&
+        a.os == 1 && a.os_nq == 0 && a.OH2 == a.OH && a.OW2 == a.OW && a.a_scale == nullptr && a.ln_w == nullptr))
+    return -1;
+  if (!(a.N == 32 || a.N == 64 || a.N == 96) || a.N2 <= 0 || a.N2 % 32 != 0 || a.N2 > a.N) return -1;
+  if (a.K % 8 != 0 || a.c_total % 8 != 0 || a.c_off % 8 != 0 || a.ldo2 % 4 != 0 || a.o_off2 % 4 != 0 || ((uintptr_t)a.Out2 & 15) != 0) return -1;
+  if (a.out_fmt2 == 1 && (a.ldo2 % 8 != 0 || a.o_off2 % 8 != 0)) return -1;
+  if (is_conv(a) && (a.stride_w > 0 || a.Cin % 8 != 0)) return -1;
+  if (!sp8_lookup(a.W, a.K, nullptr, nullptr) || !sp8_lookup(a.W2, a.N, nullptr, nullptr)) return -1;
+  return a.N == 32 ? 4 : (a.N == 64 ? 3 : 2);
+}
+bool gemm_sp_chain_ok(const GemmArgs& a) { return chain_cfg(a) >= 0; }
+
 SpPlan gemm_sp_plan(const GemmArgs& a) {
   SpPlan pl;
+  if (a.W2 != nullptr) {
+    const int c = chain_cfg(a);
+    MTGV_CHECK(c >= 0, ERR_INVALID, "gemm: this launch cannot chain its second layer (M=%d N=%d K=%d N2=%d): ask gemm_sp_chain_ok first", a.M,
+               a.N, a.K, a.N2);
+    const SpCfg& k = kCfg[c];
+    pl.cfg = c, pl.bm = k.bm(), pl.bn = k.bn(), pl.unit_rows = 32 * k.tm;
+    pl.tiles_m = ceil_div(a.M, k.bm()), pl.tiles_n = 1;
+    return pl;
+  }
   const bool sp8_in = a.a_fmt == 1;
   auto none = [&]() -> SpPlan {
     MTGV_CHECK(!sp8_in && a.out_fmt == 0 && a.res_fmt == 0, ERR_INVALID,
@@ -416,6 +442,13 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
   g.d_kw = make_fastdiv((uint32_t)a.KW);
   g.remap = !(a.os == 1 && a.oy == 0 && a.ox == 0 && a.OH2 == a.OH && a.OW2 == a.OW);
   g.os = a.os, g.oy = a.oy, g.ox = a.ox, g.OH2 = a.OH2, g.OW2 = a.OW2;
+  if (a.W2 != nullptr) {
+    const char* w28 = nullptr;
+    const float* w2s = nullptr;
+    MTGV_CHECK(sp8_lookup(a.W2, a.N, &w28, &w2s), ERR_RUNTIME, "gemm_sp: second-layer weights lost their SP8 copy");
+    g.W2 = w28, g.wscale2 = w2s, g.bias2 = a.bias2, g.Out2 = a.Out2, g.ldo2 = a.ldo2, g.o_off2 = a.o_off2, g.out_fmt2 = a.out_fmt2;
+    g.act2 = a.act2, g.N2 = a.N2;
+  }
   g.nq = a.os_nq;
   g.d_nq = make_fastdiv((uint32_t)(a.os_nq > 0 ? a.os_nq : 1)), g.d_os = make_fastdiv((uint32_t)(a.os > 0 ? a.os : 1));
   if (a.os_nq > 0)

@@ -21,17 +21,20 @@ void sp_launch_nst(const SpDev& g, hipStream_t s) {
   constexpr int BM = 32 * SP_TM * SP_WM, BN = 32 * SP_TN * SP_WN;
   constexpr size_t ring = (size_t)NST * ((AMODE == 5 ? BN : BM + BN) * 64 * SP_KS + (AMODE == 3 ? 1024 : 0));
   size_t lds = ring;
+  // chained 1x1 (EPI 32): after the main loop the block holds one accumulator column block and TN A2 stages per wave and W2
+  constexpr size_t chain_lds = (size_t)SP_WM * SP_WN * 4096 * (1 + SP_TN) + (size_t)SP_TN * 96 * 128;
   if (AMODE == 5) {  // window of BM + 2 W + 2 pixels x (64 KS) B in front of the weight ring; the epilogue stages 32 rows per wave
     constexpr int RB = 64 * SP_KS, RPP = 1024 / RB;
     const size_t win = (size_t)((BM + 2 * g.Wd + 2 + RPP - 1) / RPP * RPP) * RB;
     const size_t stage = (size_t)SP_WM * SP_WN * 32 * 128 * SP_TN;
     lds = win + ring > stage ? win + ring : stage;
   }
+  if (EPI == 32 && lds < chain_lds) lds = chain_lds;
   static bool attr_done_dev[MTGV_MAX_DEVICES] = {};  // hipFuncSetAttribute is per device
   bool& attr_done = attr_done_dev[current_device()];
   auto kern = gemm_sp_kernel<SP_WM, SP_WN, SP_TM, SP_TN, SP_KS, NST, AMODE, ACT, EPI>;
   if (!attr_done) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AMODE == 5 ? 160 * 1024 : (int)lds));
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (AMODE == 5 || EPI == 32) ? 160 * 1024 : (int)lds));
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(64 * SP_WM * SP_WN), lds, s, g);
@@ -56,13 +59,15 @@ void sp_launch_one(const SpDev& g, hipStream_t s) {
 
 // the compile-time epilogue shape of a launch (gemm_sp_kernel.h, EPI), or -1 when only the generic one fits
 int sp_epi_of(const SpDev& g) {
+  if (g.W2 != nullptr) return 32;  // chained 1x1
   if (g.remap || g.N % 4 != 0) return -1;
   return (g.out_fmt == 1 ? 1 : 0) | (g.res != nullptr ? (g.res_fmt == 1 ? 4 : 2) : 0) | (g.grn_part != nullptr ? 8 : 0);
 }
 
 // launches the instance whose EPI equals `epi` if it is one of those listed, the generic one otherwise
 template <int AMODE, int ACT>
-void sp_pick(const SpDev& g, int, hipStream_t s) {
+void sp_pick(const SpDev& g, int epi, hipStream_t s) {
+  MTGV_CHECK(epi != 32, ERR_RUNTIME, "gemm_sp: no chained-1x1 instance for A mode %d in configuration %d", AMODE, SP_CFG_ID);
   sp_launch_one<AMODE, ACT, -1>(g, s);
 }
 template <int AMODE, int ACT, int E0, int... ES>
@@ -131,7 +136,11 @@ void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_
   } else if (amode == 5) {
 #if SP_NST == 2
     switch (g.act) {
+#if SP_WN == 1 && SP_TM == 1
+      case ACT_SILU: sp_pick<5, ACT_SILU, 1, 5, 32>(g, epi, s); break;
+#else
       case ACT_SILU: sp_pick<5, ACT_SILU, 1, 5>(g, epi, s); break;
+#endif
       default: sp_pick<5, -1>(g, epi, s); break;
     }
 #else
@@ -140,7 +149,11 @@ void SP_CAT(gemm_sp_launch_cfg, SP_CFG_ID)(const SpDev& g, int amode, hipStream_
   } else {
     switch (g.act) {
       case ACT_NONE: sp_pick<2, ACT_NONE, 0, 1>(g, epi, s); break;
+#if SP_WN == 1 && SP_TM == 1
+      case ACT_SILU: sp_pick<2, ACT_SILU, 1, 5, 32>(g, epi, s); break;
+#else
       case ACT_SILU: sp_pick<2, ACT_SILU, 1, 5>(g, epi, s); break;
+#endif
       default: sp_pick<2, -1>(g, epi, s); break;
     }
   }

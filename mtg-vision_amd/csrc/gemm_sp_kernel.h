@@ -17,6 +17,13 @@
 //   A, AMODE 3 / 4       f32 rows by LDS-DMA; the wave that feeds a fragment to the MFMAs multiplies it by the per-image
 //                        multipliers (AMODE 3: GRN apply, convnextv2.py:171-174; one extra 1 KB DMA piece per stage holds
 //                        [8 images][32 k]) and splits it into hi / lo on the spot.
+//   EPI 32 (chain)       a following 1x1 conv / Linear whose input is this launch's whole output row (N == BN <= 96, one wave
+//                        holds all N columns of its 32 rows: WN == 1) runs inside the epilogue: the activated values are
+//                        split into SP8 pieces and written to LDS as the wave's own A stages, W2 arrives by DMA while
+//                        that happens, a second MFMA pass multiplies them and a second read-back stores Out2 - the first
+//                        layer's output never goes to HBM (detector: C2f cv1 behind a stride-2 conv, Proto cv3 behind
+//                        cv2, the heads' final 1x1 behind their 3x3).  Same SP8 values, same product order as two
+//                        launches: bit-identical.
 //   A, AMODE 6 (HI16)    A and B are plain fp16 rows (the hi halves only, 2 bytes per element): a stage is 64 k, one MFMA
 //                        per k16 step.  The approximate first pass of the bank match (match.hip); K % 64 == 0.
 //   A, AMODE 1 (REG)     f32 rows: global -> VGPR (issued before the stage's MFMAs) -> optional per-image multiplier
@@ -81,6 +88,14 @@ struct SpDev {
   int remap = 0, os = 1, oy = 0, ox = 0, OH2 = 1, OW2 = 1;
   int nq = 0;      // > 0: column group q = n / nq scatters to (oy, ox) = (q / os, q % os), channel n % nq (GemmArgs::os_nq)
   FastDiv d_nq, d_os;
+  // EPI 32 (chained 1x1): Out2[m][o_off2 + n2] = act2( sum_n act(this launch's output)[m][n] * W2[n2][n] * wscale2[n2] + bias2[n2] );
+  // the first layer's output is not stored.  N == BN (one column tile), N2 % 32 == 0, N2 <= N.
+  const char* W2 = nullptr;        // SP8 [N2][N]
+  const float* wscale2 = nullptr;  // [N2]
+  const float* bias2 = nullptr;    // [N2] or null
+  float* Out2 = nullptr;
+  long ldo2 = 0;
+  int o_off2 = 0, out_fmt2 = 0, act2 = 0, N2 = 0;
 };
 
 typedef const __attribute__((address_space(1))) void* sp_gptr;
@@ -644,6 +659,107 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   };
   __builtin_amdgcn_s_barrier();  // every wave is done with the ring: it becomes the store staging area
   const long st2 = g.stamps != nullptr ? (long)__builtin_amdgcn_s_memtime() : 0;
+
+  if constexpr (EPI == 32) {
+    static_assert(EPI != 32 || (WN == 1 && TM == 1 && KS == 2 && !HI16), "chained 1x1: one wave holds whole rows");
+    // LDS after the main loop: [NW x 4 KB: one column block of each wave's accumulators][NW x TN x 4 KB: each wave's A2
+    // stages, row-major 128-byte rows with the main loop's swizzle][TN stages x N2 rows x 128 B: W2]
+    constexpr int CB = 32 * 128;
+    char* const stg1 = smem + wave * CB;
+    char* const a2 = smem + NW * CB + wave * (TN * CB);
+    char* const w2 = smem + NW * CB * (1 + TN);
+    const int n2g = g.N2 >> 3;  // 8-row DMA pieces per stage
+    for (int p = wave; p < TN * n2g; p += NW) {
+      const int s = p / n2g, rg = p - s * n2g;
+      const int row = rg * 8 + (lane >> 3);
+      const int slot_s = (lane & 7) ^ ((row >> 1) & 7);
+      const char* const sp = g.W2 + (long)row * ((long)g.N * 4) + s * 128 + slot_s * 16;
+      __builtin_amdgcn_global_load_lds((sp_gptr)sp, (sp_lptr)(w2 + s * (g.N2 * 128) + rg * 1024), 16, 0, 0);
+    }
+    const int slot = lane & 7, lrow = lane >> 3;
+    const int mw0 = m0 + wm * 32;
+    if (wave_active) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + slot * 4;
+        const sp_f4 w1 = *reinterpret_cast<const sp_f4*>(g.wscale + n);
+        const sp_f4 b1 = g.bias != nullptr ? *reinterpret_cast<const sp_f4*>(g.bias + n) : sp_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<sp_f4*>(stg1 + r * 128 + (((gq * 2 + h) ^ (r & 7)) << 4)) =
+              sp_f4{acc[0][j][4 * gq], acc[0][j][4 * gq + 1], acc[0][j][4 * gq + 2], acc[0][j][4 * gq + 3]};
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 8 + lrow;
+          const sp_f4 raw = *reinterpret_cast<const sp_f4*>(stg1 + row * 128 + ((slot ^ lrow) << 4));
+          sp_f4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = activate(__builtin_fmaf(raw[e], w1[e] * g.a_unmul, b1[e]));
+          // this lane's 16-byte piece of the row's SP8 form (even quads: the chunk's hi halves, odd quads: its lo halves)
+          *reinterpret_cast<sp_f4*>(a2 + j * CB + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) =
+              __builtin_bit_cast(sp_f4, sp8_piece_from_quad(v, slot));
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // W2 has landed for every wave (each waited for its own pieces)
+    if (!wave_active) return;
+    const int tn2 = g.N2 >> 5;
+    spf16 acc2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc2[j][q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < TN; ++s) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const unsigned shi = (unsigned)(((ks * 4 + h * 2 + 0) ^ swr) << 4);
+        const unsigned slo = (unsigned)(((ks * 4 + h * 2 + 1) ^ swr) << 4);
+        const sp_h8 ah = *reinterpret_cast<const sp_h8*>(a2 + s * CB + r * 128 + shi);
+        const sp_h8 al = *reinterpret_cast<const sp_h8*>(a2 + s * CB + r * 128 + slo);
+        sp_h8 bh[TN], bl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int rowb = j < tn2 ? j * 32 + r : r;  // (column blocks beyond N2 are computed on block 0's rows and dropped)
+          bh[j] = *reinterpret_cast<const sp_h8*>(w2 + s * (g.N2 * 128) + rowb * 128 + shi);
+          bl[j] = *reinterpret_cast<const sp_h8*>(w2 + s * (g.N2 * 128) + rowb * 128 + slo);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah, acc2[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al, acc2[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah, acc2[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (j >= tn2) break;
+      const int n = j * 32 + slot * 4;
+      const sp_f4 w1 = *reinterpret_cast<const sp_f4*>(g.wscale2 + n);
+      const sp_f4 b1 = g.bias2 != nullptr ? *reinterpret_cast<const sp_f4*>(g.bias2 + n) : sp_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<sp_f4*>(stg1 + r * 128 + (((gq * 2 + h) ^ (r & 7)) << 4)) =
+            sp_f4{acc2[j][4 * gq], acc2[j][4 * gq + 1], acc2[j][4 * gq + 2], acc2[j][4 * gq + 3]};
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = mw0 + it * 8 + lrow;
+        const sp_f4 raw = *reinterpret_cast<const sp_f4*>(stg1 + (it * 8 + lrow) * 128 + ((slot ^ lrow) << 4));
+        sp_f4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = __builtin_fmaf(raw[e], w1[e], b1[e]);
+          v[e] = g.act2 == ACT_SILU ? act_silu(t) : (g.act2 == ACT_NONE ? t : apply_act(t, g.act2));
+        }
+        sp_f4 piece = v;
+        if (g.out_fmt2 == 1) piece = __builtin_bit_cast(sp_f4, sp8_piece_from_quad(v, slot));  // every lane takes part
+        if (m < g.M) *reinterpret_cast<sp_f4*>(g.Out2 + (long)m * g.ldo2 + g.o_off2 + n) = piece;
+      }
+    }
+    return;
+  }
   if (!wave_active) return;
 
   if constexpr (EPI == 16) {

@@ -103,6 +103,7 @@ def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
     def run(fork, up1):
         os.environ["MTGV_DET_FORK"], os.environ["MTGV_PROTO_UP1"] = fork, up1
         os.environ["MTGV_SPPF_POOLS1"] = up1  # SPPF's three max pools as one launch, switched together with the upsample form
+        os.environ["MTGV_DET_CHAIN"] = up1    # ... and the chained 1x1 convs (C2f cv1, Proto cv3, the heads' final convs)
         try:
             out = {k: (v.clone() if v is not None else None) for k, v in det.forward(frames, True, 8).items()}
             pred, protos = det.raw_outputs(32)
@@ -110,7 +111,7 @@ def test_detector_fork_join_and_single_launch_upsample_are_bit_identical(arch):
             torch.cuda.synchronize()
             return out
         finally:
-            os.environ.pop("MTGV_DET_FORK", None), os.environ.pop("MTGV_PROTO_UP1", None), os.environ.pop("MTGV_SPPF_POOLS1", None)
+            os.environ.pop("MTGV_DET_FORK", None), os.environ.pop("MTGV_PROTO_UP1", None), os.environ.pop("MTGV_SPPF_POOLS1", None), os.environ.pop("MTGV_DET_CHAIN", None)
 
     base = run("0", "0")
     assert (base["n_det"] > 0).any()

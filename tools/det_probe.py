@@ -23,7 +23,8 @@ def timeit(fn, warm=5, it=30):
     return e0.elapsed_time(e1) / it
 
 for rep in range(2):
-    for fork, up1 in (("0", "0"), ("0", "1"), ("1", "0"), ("1", "1")):
+    for fork, up1, chain in (("0", "0", "0"), ("0", "1", "0"), ("0", "1", "1"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
         os.environ["MTGV_DET_FORK"], os.environ["MTGV_PROTO_UP1"], os.environ["MTGV_SPPF_POOLS1"] = fork, up1, up1
+        os.environ["MTGV_DET_CHAIN"] = chain
         ms = timeit(lambda: det.forward(fr, True, 8))
-        print(f"{arch} b=32 fork={fork} up1={up1}: {ms:.3f} ms  {32 / ms * 1e3:.0f} frames/s", flush=True)
+        print(f"{arch} b=32 fork={fork} up1={up1} chain={chain}: {ms:.3f} ms  {32 / ms * 1e3:.0f} frames/s", flush=True)
