@@ -11,7 +11,8 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 COMMON="--steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-one-stream --no-h2d --sustained-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/two_streams -- python3 $ROOT/bench.py $COMMON > $OUT/two_streams.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/no_overlap -- python3 $ROOT/bench.py $COMMON --no-overlap > $OUT/no_overlap.log 2>&1
+# (every kernel alone on the GPU: one pipeline stream AND the detector's internal fork-join off)
+MTGV_DET_FORK=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/no_overlap -- python3 $ROOT/bench.py $COMMON --no-overlap > $OUT/no_overlap.log 2>&1
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 MTGV_FORCE_COLLECTIVE=1 \
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/nccl1 -- python3 $ROOT/bench.py --gpus 1 $COMMON --settle-steps 16 > $OUT/nccl1.log 2>&1
 for d in two_streams no_overlap nccl1; do
