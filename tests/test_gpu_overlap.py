@@ -68,3 +68,49 @@ def test_block_beside_detector_is_bit_stable(mode, tile, _env_guard):
         torch.cuda.synchronize()
         bad += int(not torch.equal(out, ref))
     assert bad == 0, f"{bad}/20 runs of the block differ when the detector shares the GPU ({mode}, tile {tile})"
+
+
+def test_pipeline_schedules_give_identical_outputs(monkeypatch):
+    """the same batches through every schedule the pipeline has - one stream with the detector's branches in sequence
+    (MTGV_DET_FORK=0), one stream with the detector's internal fork-join, two pipeline streams (MTGV_OVERLAP=on), and both
+    of those with the frames arriving from host memory (HostFrames: a copy stream, a ring of three device buffers that the
+    de-warp releases) - bit-identical ids, scores, embeddings, crops and boxes; five batches, so the ring wraps"""
+    from mtgv import spec
+    from mtgv.detector import Detector
+    from mtgv.encoder import Encoder
+    from mtgv.matcher import Matcher
+    from mtgv.pipeline import HostFrames, Pipeline
+
+    F, K = 8, 4
+    det_cfg, enc_cfg = spec.DetectorConfig(), spec.encoder_config("cnvnxt2ae_nano")
+    g = torch.Generator(device="cuda").manual_seed(12)
+    m = Matcher(768, capacity=20_000)
+    m.add(torch.randn((20_000, 768), generator=g, device="cuda"))
+    pipe = Pipeline(Detector(det_cfg, spec.random_detector_state(det_cfg, 3), max_batch=F),
+                    Encoder(enc_cfg, spec.random_encoder_state(enc_cfg, 1), max_batch=F * K), m, K, 1, quad_source="mask")
+    batches = [torch.randint(0, 256, (F, 640, 640, 3), generator=g, device="cuda", dtype=torch.uint8) for _ in range(5)]
+    host = [b.cpu() for b in batches]
+    keys = ("ids", "scores", "z", "crops", "boxes", "n_det")
+
+    def snap(outs):
+        torch.cuda.synchronize()
+        return [{k: o[k].clone() for k in keys} for o in outs]
+
+    monkeypatch.setenv("MTGV_DET_FORK", "0")
+    monkeypatch.delenv("MTGV_OVERLAP", raising=False)
+    ref = snap([pipe.run(b) for b in batches])
+    monkeypatch.delenv("MTGV_DET_FORK")
+    src = HostFrames(host, "cuda")
+    assert all(b.is_pinned() for b in src.host) and len(src.bufs) == 3
+    got = {"one stream, fork-join": snap([pipe.run(b) for b in batches]),
+           "one stream, host frames": snap([pipe.run(ls) for ls in src.leases(5)])}
+    monkeypatch.setenv("MTGV_OVERLAP", "on")
+    assert pipe.overlap_enabled()
+    got["two streams"] = snap(pipe.run_many(batches))
+    got["two streams, host frames"] = snap(pipe.run_many(src.leases(5)))
+    got["two streams, host frames again (ring reused)"] = snap(pipe.run_many(src.leases(5)))
+    for name, outs in got.items():
+        assert len(outs) == 5
+        for i, (a, b) in enumerate(zip(ref, outs)):
+            for k in keys:
+                assert torch.equal(a[k], b[k]), (name, i, k)
