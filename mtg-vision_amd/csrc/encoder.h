@@ -37,7 +37,6 @@ struct BlockW {
 };
 struct BlockWs {
   float *t1 = nullptr, *t2 = nullptr, *hid = nullptr, *part = nullptr, *scale = nullptr, *bfold = nullptr;
-  int* cnt = nullptr;  // optional: n arrival counters, zero between launches (grn_tail.h); null: GRN finalize as its own launch
 };
 struct BlockWsSize {
   size_t t, hid, part, scale, bfold;
@@ -108,7 +107,6 @@ class Encoder {
   float *head_w_ = nullptr, *head_b_ = nullptr, *head2_w_ = nullptr, *head2_b_ = nullptr;
   // workspace
   DevBuf x0_, xa_, xb_, ws_, head_a_, head_b2_;
-  DevBuf grn_cnt_;  // max_batch arrival counters of the "last block finalizes" GRN tail (grn_tail.h): zero between launches
   DevBuf stage_[4];
   bool capture_ = false;
   int last_n_ = 0;

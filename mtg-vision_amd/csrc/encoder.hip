@@ -151,7 +151,7 @@ void run_block(const float* x, float* out, int n, int h, int w, int c, int act, 
     // narrow stage: pwconv1 + GRN + pwconv2 without the 4C hidden tensor in HBM (mlp_fused_kernel.h)
     MlpArgs m;
     m.x_sp8 = ws.t2, m.w1 = bw.w1, m.b1 = bw.b1, m.gamma = bw.gamma, m.res = x, m.out = out;
-    m.part = ws.part, m.scale = ws.scale, m.cnt = ws.cnt, m.n_img = n, m.hw = hw, m.C = c, m.act = act;
+    m.part = ws.part, m.scale = ws.scale, m.n_img = n, m.hw = hw, m.C = c, m.act = act;
     if (bw.w2p != nullptr) {
       m.w2p = bw.w2p, m.ws2 = bw.w2p_scale;
     } else {  // single-op surface: the permuted copy of W2 is made per call, in the (unused) hidden-tensor workspace
@@ -173,14 +173,12 @@ void run_block(const float* x, float* out, int n, int h, int w, int c, int act, 
   const GemmPlan p1 = gemm_plan(M, 4 * c, c, true);
   g1.hw = hw;
   g1.grn_part = ws.part;  // set before the layout is computed: which kernel takes the launch depends on it
-  g1.grn_cnt = ws.cnt, g1.grn_gamma = bw.gamma, g1.grn_scale = ws.scale;
   const GrnLayout gl = gemm_grn_layout(g1, p1);
   g1.segmax = gl.segmax;
   g1.grn_unit_rows = gl.unit_rows;
   gemm_launch(g1, p1, s);
 
-  // (the LDS-DMA kernel's last block per image has already done it when gl.tail)
-  if (!gl.tail) grn_finalize_launch(ws.part, gl, n, hw, 4 * c, bw.gamma, ws.scale, s);
+  grn_finalize_launch(ws.part, gl, n, hw, 4 * c, bw.gamma, ws.scale, s);
 
   GemmArgs g2 = linear_args(ws.hid, 4 * c, bw.w2, bw.b2, out, c, M, c, 4 * c, ACT_NONE);
   g2.res = x;
@@ -331,8 +329,6 @@ Encoder::Encoder(const mtgv_encoder_cfg& cfg) : cfg_(cfg) {
   xa_.alloc(act_max);
   xb_.alloc(act_max);
   ws_.alloc(ws_max);
-  grn_cnt_.alloc((size_t)nb + 4);
-  HIP_OK(hipMemset(grn_cnt_.p, 0, ((size_t)nb + 4) * sizeof(float)));
   head_a_.alloc((size_t)nb * std::max(z, c3) + 16);
   head_b2_.alloc((size_t)nb * std::max(z, c3) + 16);
 }
@@ -540,7 +536,6 @@ void Encoder::body(int n, float* z_out, hipStream_t s) {
     ws.part = ws.hid + z.hid;
     ws.scale = ws.part + z.part;
     ws.bfold = ws.scale + z.scale;
-    ws.cnt = reinterpret_cast<int*>(grn_cnt_.p);
     for (size_t j = 0; j < blocks_[st].size(); ++j) {
       run_block(cur, alt, n, h, w, c, act_, blocks_[st][j], ws, s);
       std::swap(cur, alt);

@@ -9,7 +9,6 @@
 // at load time.
 #pragma once
 #include "common.h"
-#include "grn_tail.h"
 
 namespace mtgv {
 
@@ -62,11 +61,6 @@ struct GemmArgs {
   int hw = 0;                   // rows per image for GRN / prologue segmentation
   int segmax = 0;
   int grn_unit_rows = 0;        // rows per partial unit the caller planned for (GrnLayout::unit_rows); 0: not checked
-  // "last block finalizes" (grn_tail.h; LDS-DMA kernel only, GrnLayout::tail says whether the launch will do it): per-image
-  // arrival counters (zero between launches), GRN gamma [N] and the multiplier table [M / hw][N] to fill
-  int* grn_cnt = nullptr;
-  const float* grn_gamma = nullptr;
-  float* grn_scale = nullptr;
   // GRN apply fused into the A load of pwconv2: a' = a * a_scale[img][k] + a_shift[k]
   const float* a_scale = nullptr;
   const float* a_shift = nullptr;
@@ -145,10 +139,7 @@ void gemm_profile_end(hipStream_t s);
 struct GrnLayout {
   int unit_rows = 0, segmax = 0;
   size_t floats = 0;
-  bool tail = false;  // the producing launch turns the partial sums into multipliers itself: no grn_finalize_launch after it
 };
-GrnFin grn_fin(const float* part, const GrnLayout& l, int hw, int N, const float* gamma, float* scale);
-bool grn_tail_enabled();  // MTGV_GRN_TAIL != 0 (read per call)
 GrnLayout gemm_grn_layout(const GemmArgs& a, const GemmPlan& p);
 // upper bound of GrnLayout::floats over every kernel / tile that could be chosen
 size_t gemm_grn_part_floats_max(int M, int N, int hw);

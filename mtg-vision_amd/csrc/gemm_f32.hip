@@ -309,14 +309,7 @@ GrnLayout gemm_grn_layout(const GemmArgs& a, const GemmPlan& p) {
     l.segmax = gemm_grn_segmax(p, hw);
   }
   l.floats = (size_t)ceil_div(a.M, l.unit_rows) * l.segmax * a.N;
-  l.tail = sp.cfg >= 0 && a.grn_cnt != nullptr && a.grn_gamma != nullptr && a.grn_scale != nullptr && grn_tail_enabled() &&
-           (size_t)(a.N + 256) * sizeof(float) <= 32 * 1024;
   return l;
-}
-
-bool grn_tail_enabled() {
-  const char* e = getenv("MTGV_GRN_TAIL");
-  return e == nullptr || atoi(e) != 0;
 }
 
 size_t gemm_grn_part_floats_max(int M, int N, int hw) {
@@ -419,9 +412,41 @@ void gemm_launch(const GemmArgs& a, const GemmPlan& pl, hipStream_t s) {
 // ---------------------------------------------------------------------------
 // GRN finalize: partials -> per-(image, channel) multiplier.  One block per image.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grn_finalize_kernel(const GrnFin f) {
+__global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restrict__ part, int bm, int segmax, int hw, int N,
+                                                          FastDiv d_hw, FastDiv d_bm, const float* __restrict__ gamma,
+                                                          float* __restrict__ scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  grn_finalize_image<false>(f, blockIdx.x, sm, threadIdx.x);
+  float* gx = sm;        // [N]
+  float* red = sm + N;   // [256]
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int t_first = (int)fdiv((uint32_t)(img * hw), d_bm);
+  const int t_last = (int)fdiv((uint32_t)((img + 1) * hw - 1), d_bm);
+  float local = 0.f;
+  for (int n = tid; n < N; n += 256) {
+    float sum = 0.f;
+    for (int t0 = t_first; t0 <= t_last; t0 += 8) {  // 8 loads in flight, added in unit order (same sum as one by one)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u;
+        const int seg = img - (int)fdiv((uint32_t)(t * bm), d_hw);
+        v[u] = t <= t_last ? part[((long)t * segmax + seg) * N + n] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    const float gval = sqrtf(sum);
+    gx[n] = gval;
+    local += gval;
+  }
+  red[tid] = local;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  const float denom = red[0] / (float)N + 1e-6f;
+  for (int n = tid; n < N; n += 256) scale[(long)img * N + n] = gamma[n] * (gx[n] / denom) + 1.0f;
 }
 
 // out[n] = bias[n] + sum_k W[n][k] * shift[k]: folds GRN's "+ beta" into the bias of the Linear that follows
@@ -442,19 +467,12 @@ void fold_shift_into_bias_launch(const float* W, const float* shift, const float
   HIP_OK(hipGetLastError());
 }
 
-GrnFin grn_fin(const float* part, const GrnLayout& l, int hw, int N, const float* gamma, float* scale) {
-  GrnFin f;
-  f.part = part, f.unit_rows = l.unit_rows, f.segmax = l.segmax, f.hw = hw, f.N = N;
-  f.d_hw = make_fastdiv((uint32_t)hw), f.d_unit = make_fastdiv((uint32_t)l.unit_rows);
-  f.gamma = gamma, f.scale = scale;
-  return f;
-}
-
 void grn_finalize_launch(const float* part, const GrnLayout& l, int n_img, int hw, int N, const float* gamma, float* scale,
                          hipStream_t s) {
   const size_t lds = (size_t)(N + 256) * sizeof(float);
   MTGV_CHECK(lds <= 160 * 1024, ERR_INVALID, "grn_finalize: N=%d too large", N);
-  hipLaunchKernelGGL(grn_finalize_kernel, dim3(n_img), dim3(256), lds, s, grn_fin(part, l, hw, N, gamma, scale));
+  hipLaunchKernelGGL(grn_finalize_kernel, dim3(n_img), dim3(256), lds, s, part, l.unit_rows, l.segmax, hw, N,
+                     make_fastdiv((uint32_t)hw), make_fastdiv((uint32_t)l.unit_rows), gamma, scale);
   HIP_OK(hipGetLastError());
 }
 

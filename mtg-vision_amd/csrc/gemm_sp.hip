@@ -455,13 +455,6 @@ void gemm_sp_launch(const GemmArgs& a, const SpPlan& pl, hipStream_t s) {
     MTGV_CHECK(g.remap && a.os_nq % 8 == 0 && a.N == a.os * a.os * a.os_nq && a.oy == 0 && a.ox == 0 && a.res == nullptr &&
                    a.grn_part == nullptr,
                ERR_INVALID, "gemm_sp: os_nq=%d does not describe a %dx%d scatter of N=%d columns", a.os_nq, a.os, a.os, a.N);
-  if (a.grn_part != nullptr && a.grn_cnt != nullptr && a.grn_gamma != nullptr && a.grn_scale != nullptr && grn_tail_enabled() &&
-      (size_t)(a.N + 256) * sizeof(float) <= 32 * 1024) {
-    GrnLayout l;
-    l.unit_rows = pl.unit_rows, l.segmax = a.segmax;
-    g.tail.fin = grn_fin(a.grn_part, l, g.hw, a.N, a.grn_gamma, a.grn_scale);
-    g.tail.cnt = a.grn_cnt;
-  }
   if (a.grn_part != nullptr) {
     MTGV_CHECK(a.segmax >= (pl.unit_rows - 1) / g.hw + 2, ERR_INVALID, "gemm_sp: segmax %d too small", a.segmax);
     // the caller sized and will reduce the partial sums for the unit it planned with (gemm_grn_layout)

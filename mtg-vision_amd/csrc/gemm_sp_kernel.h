@@ -73,7 +73,6 @@ struct SpDev {
   int out_fmt = 0;              // 0: f32, 1: SP8
   int M = 0, N = 0, K = 0;
   float* grn_part = nullptr;    // [units][segmax][N], unit = one wave's rows (32*TM)
-  GrnTail tail;                 // cnt != nullptr: the block that completes an image's partial sums finalizes it (grn_tail.h)
   int hw = 1, segmax = 0;
   FastDiv d_hw;
   const float* a_scale = nullptr;  // AMODE 1: [M/hw][K]
@@ -1023,11 +1022,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-  }
-  if constexpr (GEN || (EPI & 8) != 0) {
-    // (waves whose rows lie beyond M left before the epilogue: a finished wave no longer takes part in block barriers)
-    if (grn && g.tail.cnt != nullptr)
-      grn_tail(g.tail, m0, (m0 + BM < g.M ? m0 + BM : g.M) - 1, BM, g.tiles_n, reinterpret_cast<float*>(smem));
   }
   if (g.stamps != nullptr && wave == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile's stores have been accepted

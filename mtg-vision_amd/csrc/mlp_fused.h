@@ -25,8 +25,6 @@ struct MlpArgs {
   float* out = nullptr;
   float* part = nullptr;         // >= (M / 32) * 4C floats
   float* scale = nullptr;        // >= n_img * 4C floats
-  int* cnt = nullptr;            // optional: n_img arrival counters (zero between launches) -> the statistics pass finalizes
-                                 // GRN itself (grn_tail.h) and no grn_finalize launch is made
   int n_img = 0, hw = 0, C = 0, act = 0;
 };
 // pass 1 -> grn_finalize -> pass 2 on stream s

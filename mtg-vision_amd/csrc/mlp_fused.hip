@@ -78,17 +78,11 @@ void mlp_fused_launch(const MlpArgs& a, hipStream_t s) {
   r1.M = M, r1.N = H4, r1.K = a.C, r1.act = a.act, r1.grn_part = a.part;
   const double wbytes = 2.0 * H4 * a.C * 4.0, tiles = (double)ceil_div(M, 128);
   gemm_profile_begin(r1, s, 2, tiles * (H4 * a.C * 4.0), 4.0 * ((double)M * a.C + (double)H4 * a.C + (double)(M / 32) * H4));
-  GrnLayout gl;
-  gl.unit_rows = 32, gl.segmax = 1, gl.floats = (size_t)(M / 32) * H4;
-  const bool tail = a.cnt != nullptr && grn_tail_enabled();
-  if (tail) {
-    g.tail.fin = grn_fin(a.part, gl, a.hw, H4, a.gamma, a.scale);
-    g.tail.cnt = a.cnt;
-  }
   launch_any<1>(g, a.C, a.act, s);
   gemm_profile_end(s);
-  g.tail.cnt = nullptr;
-  if (!tail) grn_finalize_launch(a.part, gl, a.n_img, a.hw, H4, a.gamma, a.scale, s);
+  GrnLayout gl;
+  gl.unit_rows = 32, gl.segmax = 1, gl.floats = (size_t)(M / 32) * H4;
+  grn_finalize_launch(a.part, gl, a.n_img, a.hw, H4, a.gamma, a.scale, s);
   GemmArgs r2;
   r2.M = M, r2.N = a.C, r2.K = H4, r2.a_scale = a.scale, r2.res = a.res;
   gemm_profile_begin(r2, s, 2, tiles * wbytes, 4.0 * (3.0 * (double)M * a.C + 2.0 * H4 * a.C));

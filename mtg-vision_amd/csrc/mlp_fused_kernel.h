@@ -33,7 +33,6 @@
 #include <type_traits>
 
 #include "act.h"
-#include "grn_tail.h"
 #include "sp8.h"
 
 namespace mtgv {
@@ -54,7 +53,6 @@ struct MlpDev {
   const float* res = nullptr;   // [M][C] f32
   float* Out = nullptr;         // [M][C] f32
   float* part = nullptr;        // PASS 1: [M / 32][4C]
-  GrnTail tail;                 // PASS 1: cnt != nullptr -> the block that completes an image finalizes it (grn_tail.h)
   const char* zero = nullptr;   // >= 16 zero bytes
   long* stamps = nullptr;       // tuning aid (MTGV_MLP_STAMPS): [tile][8] clock stamps and wait sums of wave 0
   int M = 0, hw = 1, n_img = 1;
@@ -224,10 +222,6 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpDev g) {
         __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, 10, 0);
       }
       acc = nxt;
-    }
-    if (g.tail.cnt != nullptr) {
-      __builtin_amdgcn_s_barrier();  // every wave is done with the weight ring: it becomes the finalize scratch
-      grn_tail(g.tail, m0, (m0 + BM < g.M ? m0 + BM : g.M) - 1, BM, 1, reinterpret_cast<float*>(smem));
     }
   } else {
     // slots: W1(0), then W2(j), W1(j + 1) per chunk; ring of 6, four slots (two iterations) in flight

@@ -139,29 +139,3 @@ def test_graph_replay_equals_eager():
     enc.load_state_dict(sd2)  # same buffers, new contents: the captured graph must see them
     fresh = Encoder(cfg, sd2, max_batch=8)
     assert torch.equal(enc.encode(x), fresh.encode(x))
-
-
-@pytest.mark.parametrize("name,hw,batches", [("cnvnxt2ae_tiny", (192, 128), (256, 7, 256)), ("cnvnxt2ae_nano", (192, 128), (33,)),
-                                             ("convnextv2_tiny", (224, 224), (20,))])
-def test_grn_tail_equals_the_separate_finalize_launch(name, hw, batches):
-    """GRN multipliers computed by the last pwconv1 block of each image (grn_tail.h: fence, per-image arrival counter, the
-    completing block finalizes) against the separate grn_finalize launch (MTGV_GRN_TAIL=0): the same bits, for full and ragged
-    batches, repeatedly (the counters must return to zero by themselves) and across batch sizes on one handle"""
-    import os
-
-    from mtgv import spec
-    from mtgv.encoder import Encoder
-
-    cfg = spec.encoder_config(name, hw)
-    enc = Encoder(cfg, spec.random_encoder_state(cfg, 1), max_batch=max(batches))
-    g = torch.Generator(device="cuda").manual_seed(3)
-    for b in batches:
-        x = torch.randint(0, 256, (b, *hw, 3), generator=g, device="cuda", dtype=torch.uint8)
-        os.environ["MTGV_GRN_TAIL"] = "0"
-        try:
-            ref = enc.encode(x).clone()
-        finally:
-            os.environ.pop("MTGV_GRN_TAIL")
-        for rep in range(3):
-            z = enc.encode(x)
-            assert torch.isfinite(z).all() and torch.equal(z, ref), (name, b, rep, (z - ref).abs().max().item())
