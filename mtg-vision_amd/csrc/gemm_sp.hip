@@ -307,6 +307,8 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
       if (best < 0 || cost < best_cost) best = c, best_cost = cost;
     }
   }
+  // the whole-ConvTranspose launch (os_nq column groups of 64): one group per 128 x 64 tile measured 9 % faster than 128 x 128
+  if (a.os_nq == 64 && getenv("MTGV_SP_CFG") == nullptr) best = 3;
   {  // 3x3 / stride-1 convs with 16-channel slices (Cin % 32 != 0): the window conv in 16-k stages instead of nine tap gathers
     static const bool on6 = [] { const char* e = getenv("MTGV_SP_WIN16"); return e == nullptr || atoi(e) != 0; }();
     SpPlan p6;
@@ -316,7 +318,9 @@ SpPlan gemm_sp_plan(const GemmArgs& a) {
   {  // eight-wave twin of the 128 x 192 tile (four waves per SIMD) for pwconv1-shaped launches: SP8 rows in, activation
      // + GRN sums out; measured -3..-4 % on the stage 2-3 layers, nothing on the others (MTGV_SP_CFG8=0: off)
     static const bool on8 = [] { const char* e = getenv("MTGV_SP_CFG8"); return e == nullptr || atoi(e) != 0; }();
-    if (on8 && best == 1 && !conv && sp8_in && a.grn_part != nullptr && a.topk == 0 && a.K >= 256) best = 5;
+    // (not below 12288 rows: 6144 x 3072 x 768, the stage-3 pwconv1, is 8 % faster on the four-wave tile -
+    // tools/sp_cfg_sweep.py, profiles/r04_sp_cfg_sweep.txt)
+    if (on8 && best == 1 && !conv && sp8_in && a.grn_part != nullptr && a.topk == 0 && a.K >= 256 && a.M >= 12288) best = 5;
   }
   const SpCfg& k = kCfg[best];
   pl.cfg = best;
