@@ -19,8 +19,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "mtgv", "libmtgv.so")
+# Experiments: MTGV_BUILD_TAG=x MTGV_BUILD_DEFS="-DFOO=1 ..." builds build_x/*.o -> mtgv/libmtgv_x.so beside the product
+# library (select it at run time with MTGV_LIB_PATH); without the tag this is the product build.
+_TAG = os.environ.get("MTGV_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "build" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(HERE, "mtgv", "libmtgv" + ("_" + _TAG if _TAG else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950",
@@ -42,6 +45,7 @@ FLAGS = [
     "-target-feature",
     "-Xclang",
     "-packed-fp32-ops",
+    *os.environ.get("MTGV_BUILD_DEFS", "").split(),
 ]
 
 

@@ -51,13 +51,59 @@
 
 namespace mtgv {
 
+// Experiment switch (build-time, tools only): wave priority around the phases of a main-loop stage.
+//   MTGV_SP_PRIO == 1: s_setprio 1 while a wave issues its MFMAs; == 2: s_setprio 1 while it issues DMA and LDS reads.
+#ifndef MTGV_SP_PRIO
+#define MTGV_SP_PRIO 0
+#endif
+#define MTGV_SP_PRIO_MFMA(v) do { if (MTGV_SP_PRIO == 1) __builtin_amdgcn_s_setprio(v); } while (0)
+#define MTGV_SP_PRIO_LOAD(v) do { if (MTGV_SP_PRIO == 2) __builtin_amdgcn_s_setprio(v); } while (0)
+// Experiment switch: half-stage stagger of waves 4..7 of the eight-wave SP8 tile (MI355X_MICROARCH.md, "Two waves per SIMD",
+// item 9): those waves run their second k16 step's MFMAs right after the NEXT barrier, while waves 0..3 issue DMA and read.
+#ifndef MTGV_SP_STAGGER
+#define MTGV_SP_STAGGER 0
+#endif
+// TIMING EXPERIMENTS ONLY (results are wrong): what a dense main-loop stage pays for its operand traffic.
+//   MTGV_SP_EXP == 1: no DMA after the prologue (the loop computes on stale LDS): MFMA + LDS reads + conversion alone;
+//   MTGV_SP_EXP == 2: DMA issued as usual but never waited for (vmcnt left alone): issue cost without the latency;
+//   MTGV_SP_EXP == 3: DMA of every second stage only (half the issue cost and bytes), waits as usual.
+#ifndef MTGV_SP_EXP
+#define MTGV_SP_EXP 0
+#endif
+// Rotated main loop of the f32-A launches (pwconv2): see "rotated" below.
+#ifndef MTGV_SP_ROT
+#define MTGV_SP_ROT 0
+#endif
+
 typedef float spf16 __attribute__((ext_vector_type(16)));
+
+// One MFMA of the main loop.  MTGV_SP_MFMA16 (build-time, TIMING EXPERIMENT ONLY - the results are not the product): the
+// same operand registers and the same FLOPs issued as two v_mfma_f32_16x16x32_f16 (MI355X_MICROARCH.md, DVFS item 7: the
+// clock the chip holds under matrix load depends on the MFMA shape), each k16 step on its own half of the accumulator.
+#ifndef MTGV_SP_MFMA16
+#define MTGV_SP_MFMA16 0
+#endif
+__device__ __forceinline__ spf16 sp_mfma(sp_h8 b, sp_h8 a, spf16 c, int ks) {
+#if MTGV_SP_MFMA16
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int o = (ks & 1) * 8;
+  f4 c0 = {c[o + 0], c[o + 1], c[o + 2], c[o + 3]}, c1 = {c[o + 4], c[o + 5], c[o + 6], c[o + 7]};
+  c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c[o + e] = c0[e], c[o + 4 + e] = c1[e];
+  return c;
+#else
+  (void)ks;
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c, 0, 0, 0);
+#endif
+}
 
 struct SpDev {
   float* cand_s = nullptr;      // EPI 16 (top-k): per (row, column tile, wave column) the k best (score, column) pairs
   int* cand_i = nullptr;
   int topk = 0;
-  long* stamps = nullptr;       // tuning aid (MTGV_SP_STAMPS): [tile][8] s_memtime at entry / first stage in / loop end / exit
+  long* stamps = nullptr;       // tuning aid (MTGV_SP_STAMPS): [tile][8] s_memtime at entry / first stage in / loop end / exit, HW_ID, XCC_ID, s_memrealtime at entry / exit
   const char* A = nullptr;      // AMODE 0/2: SP8 bytes; AMODE 1: f32
   long a_rowb = 0;              // bytes per A row (pixel)
   long a_offb = 0;              // byte offset of the first channel used
@@ -131,6 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   const int r = lane & 31, h = lane >> 5;
 
   const long st0 = g.stamps != nullptr ? (long)__builtin_amdgcn_s_memtime() : 0;
+  const long rt0 = g.stamps != nullptr ? (long)__builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz, clock-independent
   long st1 = 0;
   int L;
   {
@@ -393,6 +440,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   const int slot = lane & 7, lrow = lane >> 3;
   sp_f4 wsc[TN], bsv[TN];
   bool col_ok[TN];
+  // (stagger experiment: waves 4..7 hold a k16 step's fragments across the barrier, so the column vectors are fetched
+  // after the main loop instead of under it - 8 TN registers)
+  constexpr bool COLVEC_LATE = (MTGV_SP_STAGGER != 0 && WM * WN == 8 && AMODE == 0 && KS == 2) ||
+                               (MTGV_SP_ROT != 0 && (AMODE == 3 || AMODE == 4) && KS == 2 && NST == 2 && TM == 1);  // (the rotated loop keeps two fragment sets)
+  auto load_colvecs = [&]() {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = nw0 + j * 32 + slot * 4;
@@ -412,6 +464,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
     wsc[j] = w1 * g.a_unmul;
     bsv[j] = b0;
   }
+  };
+  if constexpr (!COLVEC_LATE) load_colvecs();
 
 
   // a wave whose rows all lie beyond M (ragged last tile, tiny-M problems) skips its MFMAs
@@ -426,7 +480,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   auto wait_stage = [&](bool tail) {
     // steady state: everything but the AHEAD youngest stages has landed; near the end fewer stages are outstanding
     // than that, so the tail waits for all of them
-    if (AHEAD == 0 || tail) {
+    if (MTGV_SP_EXP == 2 && !tail) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (AHEAD == 0 || tail) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     } else if (my_pieces == PPW) {
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW * AHEAD) : "memory");
@@ -499,9 +555,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
             for (int j = 0; j < TN; ++j)
 #pragma unroll
               for (int i = 0; i < TM; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = sp_mfma(bl[j], ah[i], acc[i][j], ks);
+                acc[i][j] = sp_mfma(bh[j], al[i], acc[i][j], ks);
+                acc[i][j] = sp_mfma(bh[j], ah[i], acc[i][j], ks);
               }
           }
         }
@@ -510,18 +566,198 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
       }
     }
   } else {
+  bool main_done = false;
+  constexpr int ROT_NMS = 2 * 3 * TM * TN, ROT_NDP = PPW + (AMODE == 3 ? 1 : 0);
+  constexpr bool ROT = MTGV_SP_ROT != 0 && AF32 && KS == 2 && NST == 2 && !HI16 && TM == 1 && 2 * ROT_NDP <= ROT_NMS &&
+                       2 + 2 * 4 * TM <= ROT_NMS;
+  if constexpr (ROT) {
+  if (sfast && nk >= 2) {
+    main_done = true;
+    // ---- rotated main loop (f32 A rows by DMA, two-deep ring, dense launch without a K tail) ----
+    // A stage's fragments are read from LDS - and its A rows scaled and split - one iteration BEFORE its MFMAs, in the
+    // shadow of the previous stage's MFMAs: an in-order wave then never sits on its own LDS latency or conversion, and
+    // the slot of the stage being multiplied is already free, so the DMA of stage t + 2 is issued piece by piece BETWEEN
+    // the MFMAs of stage t (every second one) instead of as a block in front of them.  Same products in the same order
+    // per accumulator: bit-identical to the plain loop.  Two register sets (F0 / F1) alternate, the loop is unrolled by two.
+    struct Frag { sp_h8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN]; };
+    struct Raw { sp_f4 x, s; };  // one granule's four k of row r (and their multipliers)
+    Frag F0, F1;
+    auto read_g = [&](const char* sb, Raw& r, int gq) {
+      const int q = gq & 1, i = (gq >> 1) % TM, ks = (gq >> 1) / TM;
+      const unsigned so = (unsigned)(((ks * 4 + h * 2 + q) ^ swr) << 4);
+      r.x = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + so);
+      if constexpr (AMODE == 3) r.s = *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + q * 16);
+    };
+    auto read_b = [&](const char* sb, Frag& f) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f.bh[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + (unsigned)(((ks * 4 + h * 2 + 0) ^ swr) << 4));
+          f.bl[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + (unsigned)(((ks * 4 + h * 2 + 1) ^ swr) << 4));
+        }
+    };
+    // granule gq = (ks, i, q): four consecutive k of row r -> half of ah / al
+    auto granule = [&](const Raw& r, Frag& f, int gq) {
+      const int q = gq & 1, i = (gq >> 1) % TM, ks = (gq >> 1) / TM;
+      sp_f4 x = r.x;
+      if constexpr (AMODE == 3) x = x * r.s;
+      sp_h4 hh, ll;
+      sp8_split4_mix(x, hh, ll);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f.ah[ks][i][4 * q + e] = hh[e], f.al[ks][i][4 * q + e] = ll[e];
+    };
+    constexpr int NG = 4 * TM;             // granules per stage
+    constexpr int NMS = 2 * 3 * TM * TN;   // MFMAs per stage
+    constexpr int NDP = PPW + (AMODE == 3 ? 1 : 0);  // DMA pieces a wave may own per stage
+    auto dma_piece = [&](int u, int t, int buf) {
+      if (u < PPW) {
+        const int p = wave + NW * u;
+        if (NP % NW == 0 || p < NP)
+          sp_dma16_saddr(p < PA ? g.A + g.a_offb + (long)t * RB : g.W + (long)t * RB, off32[u],
+                         ring + buf * STG + (SA - PA * 1024) + p * 1024);
+      } else if (AMODE == 3 && wave == NP % NW) {
+        __builtin_amdgcn_global_load_lds((sp_gptr)(sc_src + (long)t * RB), (sp_lptr)(smem + buf * STG + SA + SB), 16, 0, 0);
+      }
+    };
+    auto mfma_m = [&](const Frag& c, int m) {
+      const int ks = m / (3 * TM * TN), q = m % (3 * TM * TN), p = q / (TM * TN), j = (q % (TM * TN)) / TM, i = q % TM;
+      acc[i][j] = sp_mfma(p == 0 ? c.bl[ks][j] : c.bh[ks][j], p == 1 ? c.al[ks][i] : c.ah[ks][i], acc[i][j], ks);
+    };
+    // one stage: MFMAs of stage t out of C; (NEXT) fragments of stage t + 1 into N; (DMA) pieces of stage t + 2
+    auto body = [&](auto dma_tag, auto next_tag, int t, const Frag& C, Frag& N) {
+      constexpr bool DMA = decltype(dma_tag)::value, NEXT = decltype(next_tag)::value;
+      if constexpr (NEXT) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // my pieces of stage t + 1 have landed, my reads of stage t are done
+        __builtin_amdgcn_s_barrier();                                 // ... everyone's
+      }
+      if (!wave_active) {
+        if constexpr (DMA) {
+#pragma unroll
+          for (int u = 0; u < NDP; ++u) dma_piece(u, t + 2, t & 1);
+        }
+        return;
+      }
+      const char* const sbn = ring + ((t + 1) & 1) * STG;
+      Raw r[NG];  // (granule gq's raw values live from one granule slot before its conversion)
+      if constexpr (NEXT) {
+        read_b(sbn, N);
+        read_g(sbn, r[0], 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < NMS; ++m) {
+        mfma_m(C, m);
+        if constexpr (NEXT) {
+          if (m >= 2 && (m & 1) == 0 && (m - 2) / 2 < NG) {
+            const int gq = (m - 2) / 2;
+            if (gq + 1 < NG) read_g(sbn, r[gq + 1], gq + 1);
+            granule(r[gq], N, gq);
+          }
+        }
+        if constexpr (DMA) {
+          if ((m & 1) == 1 && m / 2 < NDP) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_piece(m / 2, t + 2, t & 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    };
+    const std::true_type yes{};
+    const std::false_type no{};
+    // prologue: stage 0 has landed; stage 1 is requested; stage 0's fragments are read and converted in the open
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g.stamps != nullptr) st1 = (long)__builtin_amdgcn_s_memtime();
+    // (stage 1 was requested by the common prologue above: NST - 1 = 1 stage ahead ... that is stage 0; request stage 1 now)
+#pragma unroll
+    for (int u = 0; u < NDP; ++u) dma_piece(u, 1, 1);
+    if (wave_active) {
+      read_b(ring, F0);
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        Raw r;
+        read_g(ring, r, gq);
+        granule(r, F0, gq);
+      }
+    }
+    int t = 0;
+    for (; t + 1 < nk - 2; t += 2) {
+      body(yes, yes, t, F0, F1);
+      body(yes, yes, t + 1, F1, F0);
+    }
+    if (t < nk - 2) {          // one more stage with DMA, then the last two
+      body(yes, yes, t, F0, F1);
+      body(no, yes, t + 1, F1, F0);
+      body(no, no, t + 2, F0, F1);
+    } else {                   // t == nk - 2
+      body(no, yes, t, F0, F1);
+      body(no, no, t + 1, F1, F0);
+    }
+  }
+  }
+  if (!main_done) {
     storeA(0);
     int buf = 0;                      // ring slot of stage t
     int nbuf = NST - 1;               // ring slot of stage t + NST - 1
+    constexpr bool STGR = MTGV_SP_STAGGER != 0 && NW == 8 && AMODE == 0 && KS == 2;
+    const bool late = STGR && wave >= 4;
+    sp_h8 hah[TM], hal[TM], hbh[TN], hbl[TN];  // (stagger) the second k16 step's fragments, held across the barrier
+    auto frag_read = [&](const char* sb, int ks, sp_h8* fah, sp_h8* fal, sp_h8* fbh, sp_h8* fbl) {
+      const unsigned shi = (unsigned)(((ks * 4 + h * 2 + 0) ^ swr) << 4);
+      const unsigned slo = (unsigned)(((ks * 4 + h * 2 + 1) ^ swr) << 4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        fah[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + shi);
+        fal[i] = *reinterpret_cast<const sp_h8*>(sb + a_off[i] + slo);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        fbh[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + shi);
+        fbl[j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
+      }
+    };
+    auto frag_mfma = [&](const sp_h8* fah, const sp_h8* fal, const sp_h8* fbh, const sp_h8* fbl) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbl[j], fah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[j], fal[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[j], fah[i], acc[i][j], 0, 0, 0);
+    };
     for (int t = 0; t < nk; ++t) {
       // stage t landed: this wave's DMA pieces (vmcnt) and REG-mode ds_writes (lgkmcnt), then everyone's (barrier).
       // The barrier also says every wave has finished reading the slot of stage t - 1, which is refilled next.
       wait_stage(t + NST - 1 > nk);
       __builtin_amdgcn_s_barrier();
       if (g.stamps != nullptr && t == 0) st1 = (long)__builtin_amdgcn_s_memtime();
+      MTGV_SP_PRIO_LOAD(1);
+      if constexpr (STGR) {
+        if (late && wave_active && t > 0) {  // the previous stage's second k16 step, out of registers
+          frag_mfma(hah, hal, hbh, hbl);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       if (t + NST - 1 < nk) {
-        issue(t + NST - 1, nbuf);
+        constexpr bool LATE_DMA = MTGV_SP_EXP == 4 && AF32 && KS == 2 && !HI16;  // (issued behind the stage's LDS reads, below)
+        if (MTGV_SP_EXP != 1 && (MTGV_SP_EXP != 3 || (t & 1)) && !(LATE_DMA && wave_active)) issue(t + NST - 1, nbuf);
         loadA(t + 1);
+      }
+      if (STGR && late) {
+        if (wave_active) {
+          const char* const sb = ring + buf * STG;
+          sp_h8 ah[TM], al[TM], bh[TN], bl[TN];
+          frag_read(sb, 0, ah, al, bh, bl);
+          frag_mfma(ah, al, bh, bl);
+          frag_read(sb, 1, hah, hal, hbh, hbl);
+        }
       }
       if (wave_active && HI16) {  // four k16 steps per stage, one product each
         const char* const sb = ring + buf * STG;
@@ -536,7 +772,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   #pragma unroll
           for (int j = 0; j < TN; ++j)
   #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i][j] = sp_mfma(bh[j], ah[i], acc[i][j], ks);
         }
       }
       if constexpr (AF32 && KS == 2 && !HI16) {
@@ -546,7 +782,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
         __builtin_amdgcn_sched_barrier(0);  // the next stage's DMA above stays ahead of this stage's arithmetic
         if (wave_active) {
           const char* const sb = ring + buf * STG;
-          sp_f4 xa[2][TM][2];
+          sp_f4 xa[2][TM][2], xs[2][TM][2];
           sp_h8 bh[2][TN], bl[2][TN];
   #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
@@ -557,8 +793,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
               xa[ks][i][0] = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + shi);
               xa[ks][i][1] = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + slo);
               if constexpr (AMODE == 3) {
-                xa[ks][i][0] = xa[ks][i][0] * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
-                xa[ks][i][1] = xa[ks][i][1] * *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
+                xs[ks][i][0] = *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
+                xs[ks][i][1] = *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
               }
             }
   #pragma unroll
@@ -567,6 +803,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
               bl[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
             }
           }
+          if constexpr (MTGV_SP_EXP == 4) {  // experiment: the stage's LDS latency runs under the next stage's DMA issue
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + NST - 1 < nk) issue(t + NST - 1, nbuf);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (AMODE == 3) {
+  #pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+  #pragma unroll
+              for (int i = 0; i < TM; ++i) xa[ks][i][0] = xa[ks][i][0] * xs[ks][i][0], xa[ks][i][1] = xa[ks][i][1] * xs[ks][i][1];
+          }
+          MTGV_SP_PRIO_LOAD(0);
+          MTGV_SP_PRIO_MFMA(1);
           sp_h8 ah[2][TM], al[2][TM];
   #pragma unroll
           for (int i = 0; i < TM; ++i) sp8_split8_mix(xa[0][i][0], xa[0][i][1], ah[0][i], al[0][i]);
@@ -579,15 +828,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   #pragma unroll
             for (int j = 0; j < TN; ++j)
   #pragma unroll
-              for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
+              for (int i = 0; i < TM; ++i) acc[i][j] = sp_mfma(bl[ks][j], ah[ks][i], acc[i][j], ks);
   #pragma unroll
             for (int j = 0; j < TN; ++j)
   #pragma unroll
-              for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][j], al[ks][i], acc[i][j], 0, 0, 0);
+              for (int i = 0; i < TM; ++i) acc[i][j] = sp_mfma(bh[ks][j], al[ks][i], acc[i][j], ks);
   #pragma unroll
             for (int j = 0; j < TN; ++j)
   #pragma unroll
-              for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
+              for (int i = 0; i < TM; ++i) acc[i][j] = sp_mfma(bh[ks][j], ah[ks][i], acc[i][j], ks);
           }
           // issue order: every LDS read, the first step's conversion, then the first step's MFMAs one by one, each
           // followed by a share of the second step's conversion
@@ -596,11 +845,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
           __builtin_amdgcn_sched_group_barrier(0x002, CV * TM, 0);                                     // VALU
   #pragma unroll
           for (int q = 0; q < 3 * TM * TN; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, 1 + MTGV_SP_MFMA16, 0);  // MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, (CV * TM + 3 * TM * TN - 1) / (3 * TM * TN), 0);  // VALU
           }
+          MTGV_SP_PRIO_MFMA(0);
         }
-      } else if (wave_active && !HI16) {
+      } else if (wave_active && !HI16 && !(STGR && late)) {
         const char* const sb = ring + buf * STG;
   #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -629,24 +879,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
           }
           // small cross terms first, the hi*hi product last (per accumulator); the three products of an accumulator are
           // issued TM * TN instructions apart, so no MFMA waits on the one just before it
+          if (ks == 0) { MTGV_SP_PRIO_LOAD(0); MTGV_SP_PRIO_MFMA(1); }
   #pragma unroll
           for (int j = 0; j < TN; ++j)
   #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i][j] = sp_mfma(bl[j], ah[i], acc[i][j], ks);
   #pragma unroll
           for (int j = 0; j < TN; ++j)
   #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i][j] = sp_mfma(bh[j], al[i], acc[i][j], ks);
   #pragma unroll
           for (int j = 0; j < TN; ++j)
   #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i][j] = sp_mfma(bh[j], ah[i], acc[i][j], ks);
         }
+        MTGV_SP_PRIO_MFMA(0);
       }
+      MTGV_SP_PRIO_LOAD(0);
       if (AMODE == 1 && t + 1 < nk) storeA(buf ^ 1);
       buf = buf + 1 == NST ? 0 : buf + 1;
       nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
+    if constexpr (STGR) {
+      if (late && wave_active && nk > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        frag_mfma(hah, hal, hbh, hbl);
+      }
+    }
+  }
   }
 
   // ---- epilogue ----
@@ -657,6 +917,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
     else if constexpr (ACT == ACT_SILU) return act_silu(x);
     else return apply_act(x, g.act);
   };
+  if constexpr (COLVEC_LATE) load_colvecs();
   __builtin_amdgcn_s_barrier();  // every wave is done with the ring: it becomes the store staging area
   const long st2 = g.stamps != nullptr ? (long)__builtin_amdgcn_s_memtime() : 0;
 
@@ -1031,6 +1292,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
       d[0] = st0, d[1] = st1, d[2] = st2, d[3] = st3;
       d[4] = (long)__builtin_amdgcn_s_getreg((15 << 11) | 4);   // HW_ID[15:0]: wave slot, SIMD, pipe, CU, SH, SE
       d[5] = (long)__builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID[3:0]
+      d[6] = rt0, d[7] = (long)__builtin_amdgcn_s_memrealtime();  // (st3 - st0) / (d[7] - d[6]) x 100 MHz = the shader clock held
     }
   }
 }

@@ -66,7 +66,12 @@ __device__ __forceinline__ void sp8_split8(const sp_f4 x0, const sp_f4 x1, sp_h8
 // (readfirstlane here, so that the "s" constraint never receives a value the compiler only believes to be uniform).
 __device__ __forceinline__ void sp_dma16_saddr(const char* base, uint32_t off, const char* lds) {
   const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)lds);
+#if defined(MTGV_SP_EXP) && MTGV_SP_EXP == 5
+  // TIMING EXPERIMENT ONLY: the same instruction with a quarter of its lanes - issue cost without the bytes
+  asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xffff\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+#else
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+#endif
 }
 
 // A thread that holds 4 consecutive channels (channel quad c4 of a pixel) turns them into its half of an SP8 chunk

@@ -30,5 +30,8 @@ while off < len(data):
     ncu = len(np.unique(cu))
     percu = np.bincount(np.unique(cu, return_inverse=True)[1])
     busy = float((t3 - t0).sum()) / (span * ncu)
-    print(f"{idx:3d} {M:7d} {N:5d} {K:5d} c{cfg} a{amode} act{act} {len(a):5d} | {span/100:.1f} ticks/100 | {np.mean(t1-t0):8.0f} {np.mean(t2-t1):8.0f} {np.mean(t3-t2):8.0f} | cus {ncu} max {percu.max()} | {busy:.2f}")
+    rt = (a[:, 7] - a[:, 6]).astype(np.float64)
+    ok = rt > 0
+    clk = float(np.median((t3 - t0)[ok] / rt[ok]) * 100.0) if ok.any() else 0.0  # MHz: s_memtime ticks per 10 ns of s_memrealtime
+    print(f"{idx:3d} {M:7d} {N:5d} {K:5d} c{cfg} a{amode} act{act} {len(a):5d} | {span/100:.1f} ticks/100 | {np.mean(t1-t0):8.0f} {np.mean(t2-t1):8.0f} {np.mean(t3-t2):8.0f} | cus {ncu} max {percu.max()} | {busy:.2f} | clk {clk:.0f} MHz tile {np.median(rt[ok]) / 100 if ok.any() else 0:.1f} us")
     idx += 1
