@@ -66,13 +66,12 @@ namespace mtgv {
 // TIMING EXPERIMENTS ONLY (results are wrong): what a dense main-loop stage pays for its operand traffic.
 //   MTGV_SP_EXP == 1: no DMA after the prologue (the loop computes on stale LDS): MFMA + LDS reads + conversion alone;
 //   MTGV_SP_EXP == 2: DMA issued as usual but never waited for (vmcnt left alone): issue cost without the latency;
-//   MTGV_SP_EXP == 3: DMA of every second stage only (half the issue cost and bytes), waits as usual.
+//   MTGV_SP_EXP == 3: DMA of every second stage only (half the issue cost and bytes), waits as usual;
+//   MTGV_SP_EXP == 4: (f32 A) the next stage's DMA issued behind this stage's LDS reads instead of ahead of them (results right);
+//   MTGV_SP_EXP == 5: every dense DMA piece with a quarter of its lanes (sp8.h): the instruction count without the bytes;
+//   MTGV_SP_EXP == 6: (f32 A) no LDS reads for the GRN multipliers; 7: (f32 A) a third of the weight-fragment LDS reads.
 #ifndef MTGV_SP_EXP
 #define MTGV_SP_EXP 0
-#endif
-// Rotated main loop of the f32-A launches (pwconv2): see "rotated" below.
-#ifndef MTGV_SP_ROT
-#define MTGV_SP_ROT 0
 #endif
 
 typedef float spf16 __attribute__((ext_vector_type(16)));
@@ -442,8 +441,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
   bool col_ok[TN];
   // (stagger experiment: waves 4..7 hold a k16 step's fragments across the barrier, so the column vectors are fetched
   // after the main loop instead of under it - 8 TN registers)
-  constexpr bool COLVEC_LATE = (MTGV_SP_STAGGER != 0 && WM * WN == 8 && AMODE == 0 && KS == 2) ||
-                               (MTGV_SP_ROT != 0 && (AMODE == 3 || AMODE == 4) && KS == 2 && NST == 2 && TM == 1);  // (the rotated loop keeps two fragment sets)
+  constexpr bool COLVEC_LATE = MTGV_SP_STAGGER != 0 && WM * WN == 8 && AMODE == 0 && KS == 2;
   auto load_colvecs = [&]() {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -566,138 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
       }
     }
   } else {
-  bool main_done = false;
-  constexpr int ROT_NMS = 2 * 3 * TM * TN, ROT_NDP = PPW + (AMODE == 3 ? 1 : 0);
-  constexpr bool ROT = MTGV_SP_ROT != 0 && AF32 && KS == 2 && NST == 2 && !HI16 && TM == 1 && 2 * ROT_NDP <= ROT_NMS &&
-                       2 + 2 * 4 * TM <= ROT_NMS;
-  if constexpr (ROT) {
-  if (sfast && nk >= 2) {
-    main_done = true;
-    // ---- rotated main loop (f32 A rows by DMA, two-deep ring, dense launch without a K tail) ----
-    // A stage's fragments are read from LDS - and its A rows scaled and split - one iteration BEFORE its MFMAs, in the
-    // shadow of the previous stage's MFMAs: an in-order wave then never sits on its own LDS latency or conversion, and
-    // the slot of the stage being multiplied is already free, so the DMA of stage t + 2 is issued piece by piece BETWEEN
-    // the MFMAs of stage t (every second one) instead of as a block in front of them.  Same products in the same order
-    // per accumulator: bit-identical to the plain loop.  Two register sets (F0 / F1) alternate, the loop is unrolled by two.
-    struct Frag { sp_h8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN]; };
-    struct Raw { sp_f4 x, s; };  // one granule's four k of row r (and their multipliers)
-    Frag F0, F1;
-    auto read_g = [&](const char* sb, Raw& r, int gq) {
-      const int q = gq & 1, i = (gq >> 1) % TM, ks = (gq >> 1) / TM;
-      const unsigned so = (unsigned)(((ks * 4 + h * 2 + q) ^ swr) << 4);
-      r.x = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + so);
-      if constexpr (AMODE == 3) r.s = *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + q * 16);
-    };
-    auto read_b = [&](const char* sb, Frag& f) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          f.bh[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + (unsigned)(((ks * 4 + h * 2 + 0) ^ swr) << 4));
-          f.bl[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + (unsigned)(((ks * 4 + h * 2 + 1) ^ swr) << 4));
-        }
-    };
-    // granule gq = (ks, i, q): four consecutive k of row r -> half of ah / al
-    auto granule = [&](const Raw& r, Frag& f, int gq) {
-      const int q = gq & 1, i = (gq >> 1) % TM, ks = (gq >> 1) / TM;
-      sp_f4 x = r.x;
-      if constexpr (AMODE == 3) x = x * r.s;
-      sp_h4 hh, ll;
-      sp8_split4_mix(x, hh, ll);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) f.ah[ks][i][4 * q + e] = hh[e], f.al[ks][i][4 * q + e] = ll[e];
-    };
-    constexpr int NG = 4 * TM;             // granules per stage
-    constexpr int NMS = 2 * 3 * TM * TN;   // MFMAs per stage
-    constexpr int NDP = PPW + (AMODE == 3 ? 1 : 0);  // DMA pieces a wave may own per stage
-    auto dma_piece = [&](int u, int t, int buf) {
-      if (u < PPW) {
-        const int p = wave + NW * u;
-        if (NP % NW == 0 || p < NP)
-          sp_dma16_saddr(p < PA ? g.A + g.a_offb + (long)t * RB : g.W + (long)t * RB, off32[u],
-                         ring + buf * STG + (SA - PA * 1024) + p * 1024);
-      } else if (AMODE == 3 && wave == NP % NW) {
-        __builtin_amdgcn_global_load_lds((sp_gptr)(sc_src + (long)t * RB), (sp_lptr)(smem + buf * STG + SA + SB), 16, 0, 0);
-      }
-    };
-    auto mfma_m = [&](const Frag& c, int m) {
-      const int ks = m / (3 * TM * TN), q = m % (3 * TM * TN), p = q / (TM * TN), j = (q % (TM * TN)) / TM, i = q % TM;
-      acc[i][j] = sp_mfma(p == 0 ? c.bl[ks][j] : c.bh[ks][j], p == 1 ? c.al[ks][i] : c.ah[ks][i], acc[i][j], ks);
-    };
-    // one stage: MFMAs of stage t out of C; (NEXT) fragments of stage t + 1 into N; (DMA) pieces of stage t + 2
-    auto body = [&](auto dma_tag, auto next_tag, int t, const Frag& C, Frag& N) {
-      constexpr bool DMA = decltype(dma_tag)::value, NEXT = decltype(next_tag)::value;
-      if constexpr (NEXT) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // my pieces of stage t + 1 have landed, my reads of stage t are done
-        __builtin_amdgcn_s_barrier();                                 // ... everyone's
-      }
-      if (!wave_active) {
-        if constexpr (DMA) {
-#pragma unroll
-          for (int u = 0; u < NDP; ++u) dma_piece(u, t + 2, t & 1);
-        }
-        return;
-      }
-      const char* const sbn = ring + ((t + 1) & 1) * STG;
-      Raw r[NG];  // (granule gq's raw values live from one granule slot before its conversion)
-      if constexpr (NEXT) {
-        read_b(sbn, N);
-        read_g(sbn, r[0], 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < NMS; ++m) {
-        mfma_m(C, m);
-        if constexpr (NEXT) {
-          if (m >= 2 && (m & 1) == 0 && (m - 2) / 2 < NG) {
-            const int gq = (m - 2) / 2;
-            if (gq + 1 < NG) read_g(sbn, r[gq + 1], gq + 1);
-            granule(r[gq], N, gq);
-          }
-        }
-        if constexpr (DMA) {
-          if ((m & 1) == 1 && m / 2 < NDP) {
-            __builtin_amdgcn_sched_barrier(0);
-            dma_piece(m / 2, t + 2, t & 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    };
-    const std::true_type yes{};
-    const std::false_type no{};
-    // prologue: stage 0 has landed; stage 1 is requested; stage 0's fragments are read and converted in the open
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (g.stamps != nullptr) st1 = (long)__builtin_amdgcn_s_memtime();
-    // (stage 1 was requested by the common prologue above: NST - 1 = 1 stage ahead ... that is stage 0; request stage 1 now)
-#pragma unroll
-    for (int u = 0; u < NDP; ++u) dma_piece(u, 1, 1);
-    if (wave_active) {
-      read_b(ring, F0);
-#pragma unroll
-      for (int gq = 0; gq < NG; ++gq) {
-        Raw r;
-        read_g(ring, r, gq);
-        granule(r, F0, gq);
-      }
-    }
-    int t = 0;
-    for (; t + 1 < nk - 2; t += 2) {
-      body(yes, yes, t, F0, F1);
-      body(yes, yes, t + 1, F1, F0);
-    }
-    if (t < nk - 2) {          // one more stage with DMA, then the last two
-      body(yes, yes, t, F0, F1);
-      body(no, yes, t + 1, F1, F0);
-      body(no, no, t + 2, F0, F1);
-    } else {                   // t == nk - 2
-      body(no, yes, t, F0, F1);
-      body(no, no, t + 1, F1, F0);
-    }
-  }
-  }
-  if (!main_done) {
+  {
     storeA(0);
     int buf = 0;                      // ring slot of stage t
     int nbuf = NST - 1;               // ring slot of stage t + NST - 1
@@ -793,14 +660,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
               xa[ks][i][0] = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + shi);
               xa[ks][i][1] = *reinterpret_cast<const sp_f4*>(sb + a_off[i] + slo);
               if constexpr (AMODE == 3) {
-                xs[ks][i][0] = *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
-                xs[ks][i][1] = *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
+                if (MTGV_SP_EXP == 6) {  // experiment: no LDS reads for the multipliers
+                  xs[ks][i][0] = xs[ks][i][1] = sp_f4{1.f, 1.f, 1.f, 1.f};
+                } else {
+                  xs[ks][i][0] = *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64);
+                  xs[ks][i][1] = *reinterpret_cast<const sp_f4*>(sb + sc_off[i] + ks * 64 + 16);
+                }
               }
             }
   #pragma unroll
             for (int j = 0; j < TN; ++j) {
-              bh[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + shi);
-              bl[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
+              if (MTGV_SP_EXP == 7 && j > 0) {  // experiment: one column block's weight fragments for all (a third of the B reads)
+                bh[ks][j] = bh[ks][0], bl[ks][j] = bl[ks][0];
+              } else {
+                bh[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + shi);
+                bl[ks][j] = *reinterpret_cast<const sp_h8*>(sb + b_off[j] + slo);
+              }
             }
           }
           if constexpr (MTGV_SP_EXP == 4) {  // experiment: the stage's LDS latency runs under the next stage's DMA issue
