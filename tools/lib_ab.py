@@ -21,6 +21,7 @@ def kind(r):
 res = {}
 for tag in tags:
     env = dict(os.environ)
+    env.setdefault("MTGV_DET_FORK", "0")  # every launch alone on the GPU (the detector's branches in sequence)
     if tag != "base":
         env["MTGV_LIB_PATH"] = os.path.join(ROOT, "mtg-vision_amd", "mtgv", f"libmtgv_{tag}.so")
     best = {}
