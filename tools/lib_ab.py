@@ -22,11 +22,15 @@ res = {}
 for tag in tags:
     env = dict(os.environ)
     env.setdefault("MTGV_DET_FORK", "0")  # every launch alone on the GPU (the detector's branches in sequence)
-    if tag != "base":
-        env["MTGV_LIB_PATH"] = os.path.join(ROOT, "mtg-vision_amd", "mtgv", f"libmtgv_{tag}.so")
+    lib, *sets = tag.split("+")  # "base+MTGV_SP_ADIRECT=1": the product library with an environment switch
+    for kv in sets:
+        k, v = kv.split("=", 1)
+        env[k] = v
+    if lib != "base":
+        env["MTGV_LIB_PATH"] = os.path.join(ROOT, "mtg-vision_amd", "mtgv", f"libmtgv_{lib}.so")
     best = {}
     for rep in range(REPS):
-        out = os.path.join(OUT, f"{tag}_{rep}.csv")
+        out = os.path.join(OUT, f"{tag.replace('+', '_').replace('=', '')}_{rep}.csv")
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_trace.py"), out], env=env, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         for r in csv.DictReader(open(out)):
