@@ -107,6 +107,10 @@ class Pipeline:
         self._warp_ws = None
 
     def _embed_match(self, frames_u8: torch.Tensor, det, lease=None):
+        return self._embed(det, *self._crop(frames_u8, det, lease))
+
+    def _crop(self, frames_u8: torch.Tensor, det, lease=None):
+        """detections -> (boxes (F, K, 4), crops (F * K, h, w, 3) uint8): the K best boxes or mask quadrilaterals, de-warped"""
         F, K = frames_u8.shape[0], self.K
         # the K highest-confidence detections per frame (NMS output is score-descending), pad boxes where a frame has
         # fewer; every step of the glue is a library kernel (no PyTorch arithmetic on the streams of the step)
@@ -125,6 +129,10 @@ class Pipeline:
         crops = warp_quads(frames_u8, quads, frame_idx, self.encoder.cfg.image_hw, 0.05, self._warp_ws)
         if lease is not None:
             lease.done()  # the de-warp is the last reader of the frames
+        return boxes, crops
+
+    def _embed(self, det, boxes, crops):
+        F, K = boxes.shape[0], self.K
         z = self.encoder.encode(crops)
         ids, scores = self.match_fn(z, self.top_k)
         return {
@@ -148,9 +156,11 @@ class Pipeline:
         return os.environ.get("MTGV_OVERLAP", "off") == "on"
 
     def run_many(self, batches, flip_rgb: bool = True):
-        """Process a sequence of frame batches with the detect stage of batch i+1 overlapped with the
-        crop/embed/match stages of batch i on a second HIP stream.  The detector's late layers have too few
-        tiles to fill 256 CUs on their own; the encoder's GEMMs of the previous batch fill the gaps.
+        """Process a sequence of frame batches with the detect + crop stages of batch i+1 overlapped with the
+        embed + match stages of batch i on a second HIP stream (round 4: the crop stage moved to the detect stream and
+        the embed stream runs at high priority - see the comments below; +3.4 % cards/s over equal priorities with the
+        crops in front of the encoder).  The detector's late layers have too few tiles to fill 256 CUs on their own;
+        they and the latency-bound crop kernels fill what the encoder's GEMMs of the previous batch leave idle.
         Results are identical to `run` on each batch (same kernels, same order per stream).
 
         Opt-in: without MTGV_OVERLAP=on everything stays on the current stream (see overlap_enabled).  (History: with packed-FP32 VALU instructions in
@@ -163,7 +173,13 @@ class Pipeline:
             return [self.run(frames, flip_rgb) for frames in batches]
         dev = self.detector.device
         if not hasattr(self, "_s_det"):
-            self._s_det, self._s_enc = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            # The embed + match stream runs at high priority: it is the longer chain (6 of a step's 8 ms), so its kernels get the
+            # CUs as if alone and the detect + crop stream fills what they leave idle (tails, half-empty rounds, small launches)
+            # instead of sharing every CU half and half.  MTGV_STREAM_PRIO=none|det: equal priorities / the other way round.
+            prio = os.environ.get("MTGV_STREAM_PRIO", "enc")
+            self._s_det = torch.cuda.Stream(dev, priority=-1 if prio == "det" else 0)
+            self._s_enc = torch.cuda.Stream(dev, priority=-1 if prio == "enc" else 0)
+        crop_on_det = os.environ.get("MTGV_CROP_STAGE", "det") != "enc"
         cur = torch.cuda.current_stream(dev)
         self._s_det.wait_stream(cur)
         self._s_enc.wait_stream(cur)
@@ -174,17 +190,21 @@ class Pipeline:
                 with torch.cuda.stream(self._s_det):
                     frames, lease = _frames_of(item)
                     det = self.detector.forward(frames, flip_rgb, mask_rows=self.K)
+                    # the crop stage (card selection, mask -> quadrilateral, de-warp: latency-bound kernels of a few hundred
+                    # workgroups) belongs to the detect stream: beside the other stream's GEMMs it costs next to nothing, in
+                    # front of the encoder it would leave most of the GPU idle (MTGV_CROP_STAGE=enc: the round-3 split)
+                    cropped = self._crop(frames, det, lease) if crop_on_det else None
                     ev = torch.cuda.Event()
                     ev.record(self._s_det)
-                nxt = (frames, det, ev, lease)
+                nxt = (frames, det, ev, lease, cropped)
             if pending is not None:
-                pf, pdet, pev, please = pending
+                pf, pdet, pev, please, pcrop = pending
                 with torch.cuda.stream(self._s_enc):
                     self._s_enc.wait_event(pev)
-                    for t in pdet.values():
+                    for t in list(pdet.values()) + list(pcrop or ()):
                         if t is not None:
                             t.record_stream(self._s_enc)
-                    outs.append(self._embed_match(pf, pdet, please))
+                    outs.append(self._embed(pdet, *pcrop) if pcrop is not None else self._embed_match(pf, pdet, please))
             pending = nxt
         cur.wait_stream(self._s_det)
         cur.wait_stream(self._s_enc)
