@@ -4,7 +4,7 @@ OUT=$ROOT/gpurun_out/r4m; mkdir -p $OUT; cd $ROOT
 COMMON="--steps 40 --warmup 5 --settle-steps 60 --no-cpu-baseline --no-roofline --no-one-stream --no-h2d --sustained-seconds 0"
 python3 bench.py $COMMON > /dev/null 2>&1
 for rep in 1 2 3; do
-for c in enc det; do for p in none enc det; do
-  v=$(MTGV_CROP_STAGE=$c MTGV_STREAM_PRIO=$p python3 bench.py $COMMON 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print(d['value'], d['config']['ids_crc32_rank0'])")
-  echo "crop=$c prio=$p rep=$rep value=$v"
-done; done; done | tee $OUT/stream_prio2.txt
+for m in 0 1; do
+  v=$(MTGV_MATCH_STREAM=$m python3 bench.py $COMMON 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print(d['value'], d['config']['ids_crc32_rank0'])")
+  echo "match_stream=$m rep=$rep value=$v"
+done; done | tee $OUT/match_stream.txt
