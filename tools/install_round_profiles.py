@@ -10,8 +10,9 @@ src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "
 for m in ("no_overlap", "two_streams", "nccl1"):
     shutil.copy(os.path.join(src, f"{tag}_f16x3_kernel_stats_bench_{m}.csv"), dst)
     shutil.copy(os.path.join(src, f"{tag}_bench_{m}.json"), os.path.join(dst, f"{tag}_bench_f16x3_{m}_under_rocprof.json"))
-for f in (f"{tag}_sq_counters_step.txt", f"{tag}_perf_probe.txt"):
-    shutil.copy(os.path.join(src, f), dst)
+for f in (f"{tag}_sq_counters_step.txt", f"{tag}_perf_probe.txt", f"{tag}_idle_two_streams.txt", f"{tag}_idle_no_overlap.txt"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), dst)
 line = open(os.path.join(ROOT, bench)).read().strip().splitlines()[-1]
 open(os.path.join(dst, f"{tag}_bench_f16x3.json"), "w").write(line + "\n")
 if bench32:

@@ -28,6 +28,15 @@ rm -rf $ROOT/gpurun_out/pmc_traffic_f16x3/FETCH_SIZE $ROOT/gpurun_out/pmc_traffi
 tools/pmc_sq.sh $TAG > $OUT/pmc_sq.log 2>&1 || true
 cp $ROOT/gpurun_out/pmc_$TAG/summary.txt $OUT/${TAG}_sq_counters_step.txt || true
 rm -rf $ROOT/gpurun_out/pmc_$TAG/p1 $ROOT/gpurun_out/pmc_$TAG/p2 $ROOT/gpurun_out/pmc_$TAG/p3 $ROOT/gpurun_out/pmc_$TAG/p4
+# idle time / kernel concurrency of the timed region from plain kernel traces (the CSVs are large: analysed here, not kept)
+cd /tmp
+for m in two_streams no_overlap; do
+  X=""; [ $m = no_overlap ] && X="--no-overlap"
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_$m -- python3 $ROOT/bench.py --steps 20 --warmup 3 --settle-steps 16 --no-cpu-baseline --no-roofline --no-one-stream --no-h2d --sustained-seconds 0 $X > $OUT/kt_$m.log 2>&1
+  python3 $ROOT/tools/trace_idle.py $(find $OUT/kt_$m -name "*kernel_trace.csv" | head -1) 0.10 > $OUT/${TAG}_idle_$m.txt 2>&1 || true
+  rm -rf $OUT/kt_$m
+done
+cd $ROOT
 python3 tools/perf_probe.py > $OUT/${TAG}_perf_probe.txt 2>&1
 python3 tools/det_probe.py > $OUT/${TAG}_det_probe.txt 2>&1
 head -12 $OUT/${TAG}_f16x3_kernel_stats_bench_no_overlap.csv | cut -c1-160
