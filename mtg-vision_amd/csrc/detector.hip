@@ -364,6 +364,15 @@ Detector::Detector(const mtgv_detector_cfg& cfg) : cfg_(cfg) {
   MTGV_CHECK(cfg.arch == 0 || cfg.arch == 8 || cfg.arch == 11, ERR_KEY, "detector: arch=%d (8: YOLOv8n-seg, 11: YOLO11n-seg)", cfg.arch);
   const int S = cfg.imgsz;
   na_ = (S / 8) * (S / 8) + (S / 16) * (S / 16) + (S / 32) * (S / 32);
+  // The branch streams of the forward's fork-join are created with the handle, not at the first forward: the HIP runtime maps
+  // streams to its hardware queues in creation order, and branch streams created after an application's high-priority
+  // stream (mtgv.Pipeline's embed stream) ended up sharing a queue with the caller's stream - the forward on ONE stream then
+  // took 5.1 instead of 2.5 ms (tools/debug/one_stream_after_overlap.py).
+  for (int i = 0; i < NSIDE; ++i) {
+    HIP_OK(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&ev_fork_[i], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
+  }
   if (v11()) {
     head_ = "model.23";
     build_v11();
@@ -450,11 +459,6 @@ bool Detector::fork_enabled() const {
 
 hipStream_t Detector::fork_after(hipStream_t s, int i) {
   if (!fork_enabled()) return s;
-  if (side_[i] == nullptr) {
-    HIP_OK(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&ev_fork_[i], hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
-  }
   HIP_OK(hipEventRecord(ev_fork_[i], s));
   HIP_OK(hipStreamWaitEvent(side_[i], ev_fork_[i], 0));
   side_busy_[i] = true;
