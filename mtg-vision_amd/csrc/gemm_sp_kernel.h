@@ -69,7 +69,8 @@ namespace mtgv {
 //   MTGV_SP_EXP == 3: DMA of every second stage only (half the issue cost and bytes), waits as usual;
 //   MTGV_SP_EXP == 4: (f32 A) the next stage's DMA issued behind this stage's LDS reads instead of ahead of them (results right);
 //   MTGV_SP_EXP == 5: every dense DMA piece with a quarter of its lanes (sp8.h): the instruction count without the bytes;
-//   MTGV_SP_EXP == 6: (f32 A) no LDS reads for the GRN multipliers; 7: (f32 A) a third of the weight-fragment LDS reads.
+//   MTGV_SP_EXP == 6: (f32 A) no LDS reads for the GRN multipliers; 7: (f32 A) a third of the weight-fragment LDS reads;
+//   MTGV_SP_EXP == 9: (f32 A) no scaling and no hi / lo split: the 48 vector instructions of a stage gone (operands are garbage).
 #ifndef MTGV_SP_EXP
 #define MTGV_SP_EXP 0
 #endif
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
             if (t + NST - 1 < nk) issue(t + NST - 1, nbuf);
             __builtin_amdgcn_sched_barrier(0);
           }
-          if constexpr (AMODE == 3) {
+          if constexpr (AMODE == 3 && MTGV_SP_EXP != 9) {
   #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
   #pragma unroll
@@ -693,12 +694,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void gemm_sp_
           MTGV_SP_PRIO_MFMA(1);
           sp_h8 ah[2][TM], al[2][TM];
   #pragma unroll
-          for (int i = 0; i < TM; ++i) sp8_split8_mix(xa[0][i][0], xa[0][i][1], ah[0][i], al[0][i]);
+          for (int i = 0; i < TM; ++i) {
+            if (MTGV_SP_EXP == 9) ah[0][i] = __builtin_bit_cast(sp_h8, xa[0][i][0]), al[0][i] = __builtin_bit_cast(sp_h8, xa[0][i][1]);  // experiment: no conversion
+            else sp8_split8_mix(xa[0][i][0], xa[0][i][1], ah[0][i], al[0][i]);
+          }
   #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             if (ks == 0) {
   #pragma unroll
-              for (int i = 0; i < TM; ++i) sp8_split8_mix(xa[1][i][0], xa[1][i][1], ah[1][i], al[1][i]);
+              for (int i = 0; i < TM; ++i) {
+                if (MTGV_SP_EXP == 9) ah[1][i] = __builtin_bit_cast(sp_h8, xa[1][i][0]), al[1][i] = __builtin_bit_cast(sp_h8, xa[1][i][1]);
+                else sp8_split8_mix(xa[1][i][0], xa[1][i][1], ah[1][i], al[1][i]);
+              }
             }
   #pragma unroll
             for (int j = 0; j < TN; ++j)

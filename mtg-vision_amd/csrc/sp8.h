@@ -69,6 +69,12 @@ __device__ __forceinline__ void sp_dma16_saddr(const char* base, uint32_t off, c
 #if defined(MTGV_SP_EXP) && MTGV_SP_EXP == 5
   // TIMING EXPERIMENT ONLY: the same instruction with a quarter of its lanes - issue cost without the bytes
   asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xffff\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+#elif defined(MTGV_SP_EXP) && MTGV_SP_EXP == 10
+  // EXPERIMENT (results unchanged): every piece twice - twice the instructions, twice the bytes, the same data
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+#elif defined(MTGV_SP_EXP) && MTGV_SP_EXP == 11
+  // EXPERIMENT (results unchanged): every piece followed by a copy of itself with a quarter of its lanes - twice the instructions, 1.25 x the bytes
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, 0xffff\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 #else
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 #endif
