@@ -55,7 +55,7 @@ def test_bench_launches_its_own_ranks():
 
 
 def test_two_ranks_sharded_with_overlap_equal_the_replicated_ids():
-    """the N > 1 default as the driver launches it - bank row-sharded, two-stream overlap ON, the exchange in its lean form
+    """the N > 1 default as the driver launches it - bank row-sharded, the overlapped schedule ON, the exchange in its lean form
     (Matcher.match_packed -> all-gather -> merge_gathered: no PyTorch arithmetic on the streams) - rehearsed with two
     ranks on one GPU (gloo): rank 0's top-1 ids over the timed steps equal those of the one-rank replicated run and of
     the one-stream run."""
@@ -71,9 +71,9 @@ def test_two_ranks_sharded_with_overlap_equal_the_replicated_ids():
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
     two = run(["--gpus", "2"])
-    assert two["n_gpus"] == 2 and "row-sharded 2-way" in two["config"]["bank_layout"] and two["config"]["streams"].startswith("2")
+    assert two["n_gpus"] == 2 and "row-sharded 2-way" in two["config"]["bank_layout"] and two["config"]["streams"].startswith("3")
     one = run(["--gpus", "1"])
-    assert one["config"]["bank_layout"] == "replicated" and one["config"]["streams"].startswith("2")
+    assert one["config"]["bank_layout"] == "replicated" and one["config"]["streams"].startswith("3")
     serial = run(["--gpus", "1", "--no-overlap"])
     assert serial["config"]["streams"] == "1"
     assert two["config"]["ids_crc32_rank0"] == one["config"]["ids_crc32_rank0"] == serial["config"]["ids_crc32_rank0"]

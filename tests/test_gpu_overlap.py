@@ -72,7 +72,7 @@ def test_block_beside_detector_is_bit_stable(mode, tile, _env_guard):
 
 def test_pipeline_schedules_give_identical_outputs(monkeypatch):
     """the same batches through every schedule the pipeline has - one stream with the detector's branches in sequence
-    (MTGV_DET_FORK=0), one stream with the detector's internal fork-join, two pipeline streams (MTGV_OVERLAP=on), and both
+    (MTGV_DET_FORK=0), one stream with the detector's internal fork-join, the overlapped schedule (MTGV_OVERLAP=on) under each of its switches, and both
     of those with the frames arriving from host memory (HostFrames: a copy stream, a ring of three device buffers that the
     de-warp releases) - bit-identical ids, scores, embeddings, crops and boxes; five batches, so the ring wraps"""
     from mtgv import spec
@@ -106,9 +106,21 @@ def test_pipeline_schedules_give_identical_outputs(monkeypatch):
            "one stream, host frames": snap([pipe.run(ls) for ls in src.leases(5)])}
     monkeypatch.setenv("MTGV_OVERLAP", "on")
     assert pipe.overlap_enabled()
-    got["two streams"] = snap(pipe.run_many(batches))
-    got["two streams, host frames"] = snap(pipe.run_many(src.leases(5)))
-    got["two streams, host frames again (ring reused)"] = snap(pipe.run_many(src.leases(5)))
+    got["overlapped (detect + crop / embed at high priority / match)"] = snap(pipe.run_many(batches))
+    got["overlapped, host frames"] = snap(pipe.run_many(src.leases(5)))
+    got["overlapped, host frames again (ring reused)"] = snap(pipe.run_many(src.leases(5)))
+    # the schedule switches of run_many (round 3's form: crops in front of the encoder, the match behind it, equal priorities)
+    monkeypatch.setenv("MTGV_CROP_STAGE", "enc")
+    got["overlapped, crop stage on the embed stream"] = snap(pipe.run_many(batches))
+    monkeypatch.setenv("MTGV_MATCH_STREAM", "0")
+    got["overlapped, crop and match on the embed stream"] = snap(pipe.run_many(batches))
+    monkeypatch.delenv("MTGV_CROP_STAGE")
+    got["overlapped, match on the embed stream"] = snap(pipe.run_many(src.leases(5)))
+    monkeypatch.delenv("MTGV_MATCH_STREAM")
+    for prio in ("none", "det"):  # (read when the streams are created)
+        monkeypatch.setenv("MTGV_STREAM_PRIO", prio)
+        del pipe._s_det, pipe._s_enc
+        got[f"overlapped, stream priority {prio}"] = snap(pipe.run_many(batches))
     for name, outs in got.items():
         assert len(outs) == 5
         for i, (a, b) in enumerate(zip(ref, outs)):
