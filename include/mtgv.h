@@ -211,6 +211,12 @@ MTGV_API int mtgv_detector_forward(mtgv_detector* h, const uint8_t* frames_dev, 
 /* raw head outputs of the last forward: pred (n, 4+nc+32, 8400) and protos (n, 32, 160, 160) */
 MTGV_API int mtgv_detector_raw(mtgv_detector* h, int32_t n, float* pred_dev, float* protos_dev, void* stream);
 MTGV_API int mtgv_detector_flops(const mtgv_detector* h, double* flops_per_frame);
+/* The forward's internal fork-join (the prototype branch and the P3 / P4 head branches on library-owned streams, see the
+ * concurrency contract above): mode 1 on, 0 off (every launch on the caller's stream), -1 the default - on unless the
+ * environment says MTGV_DET_FORK=0.  A caller that already overlaps the detector with other work on a second stream turns it
+ * off (mtgv.Pipeline.run_many does: branch streams share the runtime's few hardware queues with the caller's other streams,
+ * and a long event wait queued in one of them holds up whatever shares it; od_export.py:147-150 has no counterpart). */
+MTGV_API int mtgv_detector_set_fork(mtgv_detector* h, int32_t mode);
 /* process_mask tail: bilinear x`scale` upsample (align_corners=False) of (n, mh, mw) logits, then > 0
  * -> (n, mh*scale, mw*scale) uint8 {0,1} */
 MTGV_API int mtgv_mask_binarize(const float* logits_dev, int32_t n, int32_t mh, int32_t mw, int32_t scale, uint8_t* out_dev,

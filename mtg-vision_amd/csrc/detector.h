@@ -86,6 +86,10 @@ class Detector {
   // input exists and rejoin it before decode / the mask product.  fork_after(s, i): side stream i starts after
   // everything enqueued on s so far; join_into(s, i): s continues after everything enqueued on side stream i so far.
   bool fork_enabled() const;
+ public:
+  void set_fork(int mode) { fork_mode_ = mode; }  // -1: environment (MTGV_DET_FORK, default on), 0: off, 1: on
+ private:
+  int fork_mode_ = -1;
   hipStream_t fork_after(hipStream_t s, int i);
   void join_into(hipStream_t s, int i);
   bool v11() const { return cfg_.arch == 11; }

@@ -453,8 +453,10 @@ Detector::~Detector() {
 }
 
 bool Detector::fork_enabled() const {
+  if (count_flops_) return false;
+  if (fork_mode_ >= 0) return fork_mode_ != 0;  // mtgv_detector_set_fork
   const char* e = getenv("MTGV_DET_FORK");  // read per call: tests and tools compare both schedules in one process
-  return !count_flops_ && (e == nullptr || atoi(e) != 0);
+  return e == nullptr || atoi(e) != 0;
 }
 
 hipStream_t Detector::fork_after(hipStream_t s, int i) {
@@ -1102,6 +1104,12 @@ MTGV_API int mtgv_mask_binarize(const float* logits_dev, int32_t n, int32_t mh, 
                          out_dev, mh, mw, scale, npx);
     }
     HIP_OK(hipGetLastError());
+  });
+}
+MTGV_API int mtgv_detector_set_fork(mtgv_detector* h, int32_t mode) {
+  return guarded([&] {
+    MTGV_CHECK(h != nullptr && mode >= -1 && mode <= 1, ERR_INVALID, "mtgv_detector_set_fork: handle %p, mode %d (-1, 0, 1)", (void*)h, mode);
+    h->impl.set_fork(mode);
   });
 }
 MTGV_API int mtgv_detector_flops(const mtgv_detector* h, double* flops_per_frame) {

@@ -141,6 +141,10 @@ class Detector:
             )
         return out
 
+    def set_fork(self, mode: int):
+        """the forward's internal fork-join: 1 on, 0 off, -1 the default (on unless MTGV_DET_FORK=0); mtgv_detector_set_fork"""
+        native.check(native.lib().mtgv_detector_set_fork(self._h, int(mode)))
+
     def raw_outputs(self, n: int):
         """pred (n, 4+nc+32, 8400) and protos (n, 32, 160, 160) of the last forward (parity tests)."""
         S = self.cfg.imgsz

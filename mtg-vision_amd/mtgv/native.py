@@ -88,6 +88,7 @@ SIGNATURES = {
     "mtgv_detector_forward": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "mtgv_detector_raw": (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     "mtgv_detector_flops": (C.c_int, [c_vp, C.POINTER(C.c_double)]),
+    "mtgv_detector_set_fork": (C.c_int, [c_vp, c_i32]),
     "mtgv_mask_binarize": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mtgv_nms": (
         C.c_int,

@@ -188,17 +188,36 @@ class Pipeline:
             self._s_det = torch.cuda.Stream(dev, priority=-1 if prio == "det" else 0)
             self._s_enc = torch.cuda.Stream(dev, priority=-1 if prio == "enc" else 0)
         crop_on_det = os.environ.get("MTGV_CROP_STAGE", "det") != "enc"
-        # the match (normalise, first-pass GEMM, re-rank, merge: 0.16 ms, half of it latency-bound) on a third stream at normal
-        # priority: the next batch's encoder starts as soon as this batch's is done (MTGV_MATCH_STREAM=0: behind the encoder)
+        # the match (normalise, first-pass GEMM, re-rank, merge: 0.16 ms, half of it latency-bound) on a third stream:
+        # the next batch's encoder starts as soon as this batch's is done (MTGV_MATCH_STREAM=0: behind the encoder)
         s_match = None
         if os.environ.get("MTGV_MATCH_STREAM", "1") == "1":
             if not hasattr(self, "_s_match"):
-                self._s_match = torch.cuda.Stream(dev)
+                # (high priority like the embed stream: in the runtime's normal-priority pool its stream would share a hardware
+                # queue with another normal stream - which one depends on the order in which the application created its
+                # handles - and the match's wait for the encoder, queued long before it can be satisfied, then holds up
+                # whatever sits behind it in that queue: measured 8.3 vs 9.3 ms per step, tools/debug/enqueue_time.py)
+                self._s_match = torch.cuda.Stream(dev, priority=0 if os.environ.get("MTGV_MATCH_PRIO", "-1") == "0" else -1)
             s_match = self._s_match
             s_match.wait_stream(torch.cuda.current_stream(dev))
         cur = torch.cuda.current_stream(dev)
         self._s_det.wait_stream(cur)
         self._s_enc.wait_stream(cur)
+        # The detector's own fork-join is for the one-stream schedule (its late layers alone on 256 CUs); here the embed stream
+        # fills those gaps, and the branch streams would only add normal-priority streams to the few hardware queues:
+        # 8.05 vs 8.3 ms per step with it off, whatever the handle creation order (MTGV_OVERLAP_DET_FORK=1: left on)
+        fork_off = os.environ.get("MTGV_OVERLAP_DET_FORK", "0") != "1"
+        if fork_off:
+            self.detector.set_fork(0)
+        try:
+            return self._run_overlapped(batches, flip_rgb, crop_on_det, s_match, cur)
+        finally:
+            if fork_off:
+                self.detector.set_fork(-1)
+
+    def _run_overlapped(self, batches, flip_rgb, crop_on_det, s_match, cur):
+        import itertools
+
         outs, pending = [], None
         for item in itertools.chain(batches, [None]):  # (lazily: a HostFrames lease is issued when its turn comes)
             nxt = None

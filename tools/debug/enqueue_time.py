@@ -12,9 +12,14 @@ from mtgv.matcher import Matcher
 from mtgv.pipeline import Pipeline
 F, K = 32, 8
 det_cfg = spec.DetectorConfig(); enc_cfg = spec.encoder_config("cnvnxt2ae_tiny")
-m = Matcher(768, capacity=100_000); m.add(torch.randn((100_000, 768), device="cuda"))
-pipe = Pipeline(Detector(det_cfg, spec.random_detector_state(det_cfg, 3), max_batch=F),
-                Encoder(enc_cfg, spec.random_encoder_state(enc_cfg, 1), max_batch=F * K), m, K, 1, quad_source="mask")
+ORDER = os.environ.get("ORDER", "matcher-first")   # which handle exists (and has launched kernels) before the detector creates its branch streams
+if ORDER == "matcher-first":
+    m = Matcher(768, capacity=100_000); m.add(torch.randn((100_000, 768), device="cuda"))
+det = Detector(det_cfg, spec.random_detector_state(det_cfg, 3), max_batch=F)
+enc = Encoder(enc_cfg, spec.random_encoder_state(enc_cfg, 1), max_batch=F * K)
+if ORDER != "matcher-first":
+    m = Matcher(768, capacity=100_000); m.add(torch.randn((100_000, 768), device="cuda"))
+pipe = Pipeline(det, enc, m, K, 1, quad_source="mask")
 batches = [torch.randint(0, 256, (F, 640, 640, 3), device="cuda", dtype=torch.uint8) for _ in range(4)]
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seq = [batches[i % 4] for i in range(NS)]
