@@ -57,8 +57,8 @@ MTGV_API int mtgv_device_count(void);
  * flight can get wrong lanes.  This library is built without those instructions (every translation unit).  Streams
  * the library itself uses besides the caller's: mtgv_detector_forward forks its prototype branch and two head branches
  * onto library-owned streams and joins them before it returns control of the caller's stream (library kernels only;
- * MTGV_DET_FORK=0 keeps the forward on one stream).  mtgv.Pipeline overlaps its stages (detect + crop / embed at high
- * priority / match: three streams) only with MTGV_OVERLAP=on, and then runs nothing but library kernels on them - its output tensors are uninitialised allocations filled by the
+ * MTGV_DET_FORK=0 keeps the forward on one stream).  mtgv.Pipeline overlaps its stages (detect + crop / embed / match: three streams, the
+ * latter two at high priority, the detector's fork-join off) only with MTGV_OVERLAP=on, and then runs nothing but library kernels on them - its output tensors are uninitialised allocations filled by the
  * kernels, the glue between the stages is mtgv_select_cards - plus, with a sharded bank, RCCL's own all-gather kernels
  * (mtgv_bank_topk_packed / mtgv_topk_merge_gathered keep every other step of the exchange inside the library).  A caller
  * that runs foreign kernels (PyTorch elementwise ops included) concurrently on a second stream must either serialise

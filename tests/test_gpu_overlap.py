@@ -117,6 +117,13 @@ def test_pipeline_schedules_give_identical_outputs(monkeypatch):
     monkeypatch.delenv("MTGV_CROP_STAGE")
     got["overlapped, match on the embed stream"] = snap(pipe.run_many(src.leases(5)))
     monkeypatch.delenv("MTGV_MATCH_STREAM")
+    monkeypatch.setenv("MTGV_OVERLAP_DET_FORK", "1")  # the detector's own fork-join left on inside run_many
+    got["overlapped, detector fork-join on"] = snap(pipe.run_many(batches))
+    monkeypatch.delenv("MTGV_OVERLAP_DET_FORK")
+    monkeypatch.setenv("MTGV_MATCH_PRIO", "0")
+    del pipe._s_match
+    got["overlapped, match stream at normal priority"] = snap(pipe.run_many(batches))
+    monkeypatch.delenv("MTGV_MATCH_PRIO")
     for prio in ("none", "det"):  # (read when the streams are created)
         monkeypatch.setenv("MTGV_STREAM_PRIO", prio)
         del pipe._s_det, pipe._s_enc

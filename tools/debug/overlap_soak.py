@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: bench-sized pipeline (mask quads), every output compared bit for bit against the fully serial schedule (one stream,
-MTGV_DET_FORK=0): the overlapped run_many (detect + crop / embed at high priority / match streams) with the detector's internal fork-join on, and
+MTGV_DET_FORK=0): the overlapped run_many (detect + crop / embed / match streams, the latter two at high priority; the detector's fork-join off inside it), and
 the same with the frames arriving from pinned host memory on a copy stream (HostFrames).  MTGV_OVERLAP=on is set here."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
