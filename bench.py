@@ -311,9 +311,10 @@ def main():
             "element: weights and bank with a power-of-two scale per row, GEMM-bound activations written that way by their producers, the "
             "rest split when a fragment is read), 3 fp16 MFMAs per product, f32 accumulate (error vs fp64 at the f32 level, "
             "tests/test_gpu_precision.py)",
-            "streams": ("3 pipeline streams (detect + crop of step i+1 beside embed of step i at high priority and match of step i "
-                        "behind it; MTGV_OVERLAP=on set by bench.py, the library default is 1; switches MTGV_STREAM_PRIO, "
-                        "MTGV_CROP_STAGE, MTGV_MATCH_STREAM in mtgv/pipeline.py)") if overlap else "1",
+            "streams": ("3 pipeline streams (detect + crop of step i+1 beside embed of step i and, behind it, match of step i, the "
+                        "latter two at high priority; the detector's own fork-join off; MTGV_OVERLAP=on set by bench.py, the "
+                        "library default is 1; switches MTGV_STREAM_PRIO, MTGV_CROP_STAGE, MTGV_MATCH_STREAM, MTGV_MATCH_PRIO, "
+                        "MTGV_OVERLAP_DET_FORK in mtgv/pipeline.py)") if overlap else "1",
             "settle": f"{a.settle_steps} untimed steps ({t_settle:.1f} s of steady load) before the {a.warmup} warm-up steps of `value`; "
             "unsettled_value is the same W + K measurement taken BEFORE them, first thing on the freshly leased GPU",
             "unsettled_value": round(cards / dt_cold, 1),
