@@ -101,6 +101,9 @@ class Pipeline:
         self.detector, self.encoder, self.matcher = detector, encoder, matcher
         self.K = int(cards_per_frame)
         self.top_k = int(top_k)
+        # a caller-supplied match (bench.py: the sharded bank's local top-k + all-gathers + merge) may issue collectives, which
+        # run on the process group's own normal-priority stream: run_many then keeps every stream at normal priority (below)
+        self._plain_match = match_fn is None
         self.match_fn = match_fn or (lambda z, k: matcher.match(z, k))
         reps = (self.K + _PAD_BOXES.shape[0] - 1) // _PAD_BOXES.shape[0]
         self._pad = _PAD_BOXES.repeat(reps, 1)[: self.K].to(detector.device).contiguous()
@@ -184,7 +187,10 @@ class Pipeline:
             # The embed + match stream runs at high priority: it is the longer chain (6 of a step's 8 ms), so its kernels get the
             # CUs as if alone and the detect + crop stream fills what they leave idle (tails, half-empty rounds, small launches)
             # instead of sharing every CU half and half.  MTGV_STREAM_PRIO=none|det: equal priorities / the other way round.
-            prio = os.environ.get("MTGV_STREAM_PRIO", "enc")
+            # With a match that issues collectives (sharded bank) every stream stays at normal priority: a high-priority stream
+            # that calls into the process group - whose own stream is a normal-priority one, queued with long event waits in
+            # the hardware queues the detect stream uses - cost 19 % (world-size-1 RCCL run: 25.6k vs 31.7k cards/s; 32.0k replicated).
+            prio = os.environ.get("MTGV_STREAM_PRIO", "enc" if self._plain_match else "none")
             self._s_det = torch.cuda.Stream(dev, priority=-1 if prio == "det" else 0)
             self._s_enc = torch.cuda.Stream(dev, priority=-1 if prio == "enc" else 0)
         crop_on_det = os.environ.get("MTGV_CROP_STAGE", "det") != "enc"
@@ -197,7 +203,8 @@ class Pipeline:
                 # queue with another normal stream - which one depends on the order in which the application created its
                 # handles - and the match's wait for the encoder, queued long before it can be satisfied, then holds up
                 # whatever sits behind it in that queue: measured 8.3 vs 9.3 ms per step, tools/debug/enqueue_time.py)
-                self._s_match = torch.cuda.Stream(dev, priority=0 if os.environ.get("MTGV_MATCH_PRIO", "-1") == "0" else -1)
+                mp = os.environ.get("MTGV_MATCH_PRIO", "-1" if self._plain_match else "0")
+                self._s_match = torch.cuda.Stream(dev, priority=0 if mp == "0" else -1)
             s_match = self._s_match
             s_match.wait_stream(torch.cuda.current_stream(dev))
         cur = torch.cuda.current_stream(dev)
