@@ -167,19 +167,18 @@ class Pipeline:
         return os.environ.get("MTGV_OVERLAP", "off") == "on"
 
     def run_many(self, batches, flip_rgb: bool = True):
-        """Process a sequence of frame batches with the detect + crop stages of batch i+1 overlapped with the
-        embed + match stages of batch i on a second HIP stream (round 4: the crop stage moved to the detect stream and
-        the embed stream runs at high priority - see the comments below; +3.4 % cards/s over equal priorities with the
-        crops in front of the encoder).  The detector's late layers have too few tiles to fill 256 CUs on their own;
-        they and the latency-bound crop kernels fill what the encoder's GEMMs of the previous batch leave idle.
-        Results are identical to `run` on each batch (same kernels, same order per stream).
+        """Process a sequence of frame batches with the detect + crop stages of batch i+1 (one stream) overlapped with the
+        embed stage of batch i (a second stream) and its match (a third); with the library's own match the latter two run at
+        high priority, with a caller-supplied (collective) match all three at normal priority - the comments below and
+        DESIGN.md section 5 say why (round 4: +7 % cards/s over round 3's two equal-priority streams with the crops in front
+        of the encoder, independent of the order in which the application created its handles).  The detector's late layers
+        have too few tiles to fill 256 CUs on their own; they and the latency-bound crop kernels fill what the encoder's GEMMs
+        of the previous batch leave idle.  Results are identical to `run` on each batch (same kernels, same order per stream).
 
         Opt-in: without MTGV_OVERLAP=on everything stays on the current stream (see overlap_enabled).  (History: with packed-FP32 VALU instructions in
         the library, kernels sharing a CU with the split-precision GEMM of the other stream sporadically lost a
         packed result in one 16-lane group; the library is built without those instructions - build.py, DESIGN.md
         section 5 - and tests/test_gpu_overlap.py guards the combination.)"""
-        import itertools
-
         if not self.overlap_enabled():
             return [self.run(frames, flip_rgb) for frames in batches]
         dev = self.detector.device
