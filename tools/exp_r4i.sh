@@ -4,8 +4,6 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/r4i
 mkdir -p $OUT
 cd $ROOT
-python3 tools/power_probe.py > $OUT/power_probe.txt 2>&1; cat $OUT/power_probe.txt
-python3 tools/power_probe.py 24576 1536 384 >> $OUT/power_probe.txt 2>&1
 REPS=4 python3 tools/lib_ab.py base mfma16 base > $OUT/lib_ab_mfma16.txt 2>&1
 cat $OUT/lib_ab_mfma16.txt
 MTGV_LIB_PATH=$ROOT/mtg-vision_amd/mtgv/libmtgv_mfma16.so MTGV_SP_STAMPS=1 python3 tools/gemm_trace.py $OUT/trace_stamps16.csv > $OUT/trace_stamps16.txt 2>&1
