@@ -124,10 +124,16 @@ def test_pipeline_schedules_give_identical_outputs(monkeypatch):
     del pipe._s_match
     got["overlapped, match stream at normal priority"] = snap(pipe.run_many(batches))
     monkeypatch.delenv("MTGV_MATCH_PRIO")
+    del pipe._s_match  # (recreated at its default priority by the next run_many)
     for prio in ("none", "det"):  # (read when the streams are created)
         monkeypatch.setenv("MTGV_STREAM_PRIO", prio)
         del pipe._s_det, pipe._s_enc
         got[f"overlapped, stream priority {prio}"] = snap(pipe.run_many(batches))
+    # a caller-supplied match (the sharded bank's path): run_many keeps every stream at normal priority for it
+    pipe2 = Pipeline(pipe.detector, pipe.encoder, m, K, 1, match_fn=lambda z, k: m.match(z, k), quad_source="mask")
+    assert not pipe2._plain_match
+    got["overlapped, caller-supplied match (normal priorities)"] = snap(pipe2.run_many(batches))
+    assert pipe2._s_enc.priority == 0 and pipe2._s_match.priority == 0 and pipe._s_match.priority == -1
     for name, outs in got.items():
         assert len(outs) == 5
         for i, (a, b) in enumerate(zip(ref, outs)):
