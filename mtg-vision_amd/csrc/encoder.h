@@ -44,8 +44,17 @@ struct BlockWsSize {
 };
 BlockWsSize block_ws_size(int n, int h, int w, int c);
 // Block.forward on NHWC x -> out (may not alias x)
-void run_block(const float* x, float* out, int n, int h, int w, int c, int act, const BlockW& bw, const BlockWs& ws,
-               hipStream_t s);
+// The LayerNorm over C that follows a stage's last block (the downsample's): when the block runs fused (mlp_fused_kernel.h) its
+// output pass applies it in the epilogue and writes the normalised rows in SP8 form to `out_sp8` (which may be the block's own
+// input buffer) instead of the block output.  run_block returns true when it did so.
+struct BlockLn {
+  float* out_sp8 = nullptr;
+  const float* w = nullptr;
+  const float* b = nullptr;
+  float eps = 1e-6f;
+};
+bool run_block(const float* x, float* out, int n, int h, int w, int c, int act, const BlockW& bw, const BlockWs& ws,
+               hipStream_t s, const BlockLn* ln = nullptr);
 
 GemmArgs linear_args(const float* A, int lda, const float* W, const float* bias, float* Out, int ldo, int M, int N, int K,
                      int act);

@@ -135,8 +135,8 @@ BlockWsSize block_ws_size(int n, int h, int w, int c) {
   return z;
 }
 
-void run_block(const float* x, float* out, int n, int h, int w, int c, int act, const BlockW& bw, const BlockWs& ws,
-               hipStream_t s) {
+bool run_block(const float* x, float* out, int n, int h, int w, int c, int act, const BlockW& bw, const BlockWs& ws,
+               hipStream_t s, const BlockLn* ln) {
   const int M = n * h * w, hw = h * w;
   // the normalised tensor has one consumer, pwconv1: written in SP8 when that launch runs on the LDS-DMA kernel
   const int fmt = gemm_sp_takes_sp8(bw.w1, M, 4 * c, c, c, 0) ? 1 : 0;
@@ -164,8 +164,9 @@ void run_block(const float* x, float* out, int n, int h, int w, int c, int act, 
       fold_shift_into_bias_launch(bw.w2, bw.beta, bw.b2, ws.bfold, c, 4 * c, s);
       m.b2 = ws.bfold;
     }
+    if (ln != nullptr && ln->out_sp8 != nullptr) m.out_ln = ln->out_sp8, m.ln_w = ln->w, m.ln_b = ln->b, m.ln_eps = ln->eps;
     mlp_fused_launch(m, s);
-    return;
+    return m.out_ln != nullptr;
   }
 
   GemmArgs g1 = linear_args(ws.t2, c, bw.w1, bw.b1, ws.hid, 4 * c, M, 4 * c, c, act);
@@ -192,6 +193,7 @@ void run_block(const float* x, float* out, int n, int h, int w, int c, int act, 
     g2.bias = ws.bfold;
   }
   gemm_launch(g2, gemm_plan(M, c, 4 * c, false, true), s);
+  return false;
 }
 
 // ---------------------------------------------------------------------------
@@ -506,6 +508,9 @@ void Encoder::body(int n, float* z_out, hipStream_t s) {
     }
   }
 
+  const char* const ln_env = getenv("MTGV_LN_FUSE");  // read per call: a test compares both forms in one process
+  const bool ln_fuse = ln_env == nullptr || atoi(ln_env) != 0;
+  bool ln_done = false;
   for (int st = 0; st < 4; ++st) {
     const int h = sh_[st], w = sw_[st], c = d[st];
     if (st > 0) {
@@ -514,7 +519,13 @@ void Encoder::body(int n, float* z_out, hipStream_t s) {
       // the LayerNorm writes hi/lo-split rows when the conv runs on the LDS-DMA kernel (its 2x2 gather is then a DMA
       // source address, no conversion in the loader)
       const int fmt = gemm_sp_takes_sp8(ds_w_[st], n * h * w, c, 4 * cp, cp, 0) ? 1 : 0;
-      ln_rows_launch(cur, cp, 0, alt, cp, 0, ds_ln_w_[st], ds_ln_b_[st], (long)n * hp * wp, cp, 1e-6f, s, fmt);
+      if (ln_done) {
+        std::swap(cur, alt);  // `alt` holds LayerNorm(x) in SP8 form already (the previous stage's last block wrote it in place)
+        MTGV_CHECK(fmt == 1, ERR_RUNTIME, "encoder: fused LayerNorm output is SP8 but the downsample conv wants f32");
+      } else {
+        ln_rows_launch(cur, cp, 0, alt, cp, 0, ds_ln_w_[st], ds_ln_b_[st], (long)n * hp * wp, cp, 1e-6f, s, fmt);
+      }
+      ln_done = false;
       GemmArgs g;
       g.a_fmt = fmt;
       g.A = alt;
@@ -537,8 +548,18 @@ void Encoder::body(int n, float* z_out, hipStream_t s) {
     ws.scale = ws.part + z.part;
     ws.bfold = ws.scale + z.scale;
     for (size_t j = 0; j < blocks_[st].size(); ++j) {
-      run_block(cur, alt, n, h, w, c, act_, blocks_[st][j], ws, s);
-      std::swap(cur, alt);
+      // the stage's last block hands the downsample's LayerNorm to its fused output pass where it can (MTGV_LN_FUSE=0: off):
+      // the normalised rows replace the block's input in place and the block's f32 output is never written
+      BlockLn ln;
+      if (ln_fuse && j + 1 == blocks_[st].size() && st < 3 && !capture_ &&
+          gemm_sp_takes_sp8(ds_w_[st + 1], n * sh_[st + 1] * sw_[st + 1], d[st + 1], 4 * c, c, 0)) {
+        ln.out_sp8 = cur, ln.w = ds_ln_w_[st + 1], ln.b = ds_ln_b_[st + 1], ln.eps = 1e-6f;
+      }
+      if (run_block(cur, alt, n, h, w, c, act_, blocks_[st][j], ws, s, &ln)) {
+        ln_done = true;  // `cur` now holds LayerNorm(block output) as SP8 rows
+      } else {
+        std::swap(cur, alt);
+      }
     }
     if (capture_)
       HIP_OK(hipMemcpyAsync(stage_[st].p, cur, (size_t)n * h * w * c * sizeof(float), hipMemcpyDeviceToDevice, s));

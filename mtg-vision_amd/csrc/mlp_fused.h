@@ -26,6 +26,12 @@ struct MlpArgs {
   float* part = nullptr;         // >= (M / 32) * 4C floats
   float* scale = nullptr;        // >= n_img * 4C floats
   int n_img = 0, hw = 0, C = 0, act = 0;
+  // optional: the LayerNorm over C that follows the stage (downsample) in the output pass's epilogue - out_ln receives SP8 rows
+  // [M][C] and `out` is not written; out_ln may be the buffer `res` points into
+  float* out_ln = nullptr;
+  const float* ln_w = nullptr;
+  const float* ln_b = nullptr;
+  float ln_eps = 1e-6f;
 };
 // pass 1 -> grn_finalize -> pass 2 on stream s
 void mlp_fused_launch(const MlpArgs& a, hipStream_t s);

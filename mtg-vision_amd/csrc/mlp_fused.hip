@@ -67,6 +67,10 @@ void mlp_fused_launch(const MlpArgs& a, hipStream_t s) {
   g.W1 = w8, g.ws1 = wsc, g.b1 = a.b1;
   g.W2p = reinterpret_cast<const char*>(a.w2p), g.ws2 = a.ws2, g.b2 = a.b2;
   g.scale = a.scale, g.res = a.res, g.Out = a.out, g.part = a.part;
+  if (a.out_ln != nullptr) {
+    MTGV_CHECK(a.ln_w != nullptr && a.ln_b != nullptr, ERR_INVALID, "mlp_fused: LayerNorm epilogue without its weights");
+    g.OutLn = reinterpret_cast<char*>(a.out_ln), g.ln_w = a.ln_w, g.ln_b = a.ln_b, g.ln_eps = a.ln_eps;
+  }
   g.zero = sp_zero_page();
   g.M = M, g.hw = a.hw, g.n_img = a.n_img;
   g.d_hw = make_fastdiv((uint32_t)a.hw);

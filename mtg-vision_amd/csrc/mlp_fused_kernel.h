@@ -55,6 +55,12 @@ struct MlpDev {
   float* part = nullptr;        // PASS 1: [M / 32][4C]
   const char* zero = nullptr;   // >= 16 zero bytes
   long* stamps = nullptr;       // tuning aid (MTGV_MLP_STAMPS): [tile][8] clock stamps and wait sums of wave 0
+  // PASS 2, last block of a stage: the next layer's LayerNorm over C (the downsample's, convnextv2.py:258-263) in the epilogue -
+  // OutLn receives the normalised rows in SP8 form and Out is not written (nothing else reads the stage's last f32 output)
+  char* OutLn = nullptr;        // SP8 rows [M][C]; may alias res (a tile reads its residual rows before it stores)
+  const float* ln_w = nullptr;  // [C]
+  const float* ln_b = nullptr;  // [C]
+  float ln_eps = 1e-6f;
   int M = 0, hw = 1, n_img = 1;
   FastDiv d_hw;
 };
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpDev g) {
           if (n + 4 * h < C) rs[nb][gq] = *reinterpret_cast<const sp_f4*>(g.res + ro + n);  // C % 8 == 0: whole quads
         }
       const char* const ex2 = smem + NV * VB + h * 16;
+      if (g.OutLn == nullptr) {
 #pragma unroll
       for (int nb = 0; nb < KB; ++nb)
 #pragma unroll
@@ -332,6 +339,55 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpDev g) {
             *reinterpret_cast<sp_f4*>(g.Out + ro + n) = o;
           }
         }
+      } else {
+        // LayerNorm over the row's C outputs: the row lives in two lanes (h = 0 / 1, 4-column quads alternating), each sums its
+        // quads in ascending column order, the pair adds h = 0's part first; two-pass variance as in ln_rows_kernel.  (The
+        // values stay where the accumulators were: rs is overwritten.)
+        float s0 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < KB; ++nb)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int n = 32 * nb + 8 * gq;
+            if (n + 4 * h < C) {
+              const sp_f4 ws = *reinterpret_cast<const sp_f4*>(ex2 + n * 4);
+              const sp_f4 bs = *reinterpret_cast<const sp_f4*>(ex2 + C * 4 + n * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) rs[nb][gq][e] = __builtin_fmaf(acc2[nb][4 * gq + e], ws[e], bs[e]) + rs[nb][gq][e];
+              s0 += (rs[nb][gq][0] + rs[nb][gq][1]) + (rs[nb][gq][2] + rs[nb][gq][3]);
+            }
+          }
+        const float so = __shfl_xor(s0, 32);
+        const float mean = (h == 0 ? s0 + so : so + s0) / (float)C;
+        float q0 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < KB; ++nb)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+            if (32 * nb + 8 * gq + 4 * h < C) {
+              const sp_f4 d = rs[nb][gq] - mean;
+              q0 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        const float qo = __shfl_xor(q0, 32);
+        const float rstd = 1.0f / sqrtf((h == 0 ? q0 + qo : qo + q0) / (float)C + g.ln_eps);
+        char* const orow = g.OutLn + (long)mrow * (C * 4);
+#pragma unroll
+        for (int nb = 0; nb < KB; ++nb)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int n = 32 * nb + 8 * gq + 4 * h;
+            if (n < C) {
+              const sp_f4 wv = *reinterpret_cast<const sp_f4*>(g.ln_w + n), bv = *reinterpret_cast<const sp_f4*>(g.ln_b + n);
+              const sp_f4 y = (rs[nb][gq] - mean) * rstd * wv + bv;
+              sp_h4 hi, lo;
+              sp8_split4(y, hi, lo);
+              // chunk (n / 8) = [8 hi halves | 8 lo halves]: this lane holds positions 4 h .. 4 h + 3 of each
+              char* const cb = orow + (n >> 3) * 32 + h * 8;
+              *reinterpret_cast<sp_h4*>(cb) = hi;
+              *reinterpret_cast<sp_h4*>(cb + 16) = lo;
+            }
+          }
+      }
     }
     if (stamp && wave == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -58,6 +58,29 @@ def test_full_config_z(name):
     assert e64 < TOL and e32 < TOL
 
 
+@pytest.mark.parametrize("name", FULL)
+def test_downsample_layernorm_in_the_fused_epilogue(name, monkeypatch):
+    """the last block of a narrow stage applies the downsample's LayerNorm (convnextv2.py:258-263) in its fused output pass
+    and writes SP8 rows in place of its input (MTGV_LN_FUSE, default on); with it off the block output is written and
+    ln_rows_kernel normalises it.  The two forms sum a row's C values in different orders: equal within 1e-5 at the embedding (measured 3.6e-6), both
+    within the contract of the reference's fp64 output."""
+    from mtgv import native, spec
+    from mtgv.encoder import Encoder
+
+    if native.get_gemm_precision() != "f16x3":
+        pytest.skip("the fused MLP kernel belongs to the f16x3 operand mode")
+    g = np.load(os.path.join(GOLDEN, f"encoder_{name}.npz"))
+    cfg = _cfg(g)
+    enc = Encoder(cfg, spec.random_encoder_state(cfg, 1), max_batch=4)
+    x = torch.from_numpy(np.random.default_rng(0).random((4, 3, *cfg.image_hw), dtype=np.float32))
+    monkeypatch.setenv("MTGV_LN_FUSE", "1")
+    z1 = enc.encode(x).cpu().numpy()
+    monkeypatch.setenv("MTGV_LN_FUSE", "0")
+    z0 = enc.encode(x).cpu().numpy()
+    assert np.abs(z1 - z0).max() < 1e-5, np.abs(z1 - z0).max()
+    assert np.abs(z1 - g["z_fp64"]).max() < TOL and np.abs(z0 - g["z_fp64"]).max() < TOL
+
+
 def test_batching_layouts_and_predict():
     """batch > max_batch is chunked; NCHW f32 / NHWC f32 / NHWC u8 inputs agree; predict() contract."""
     from mtgv import spec
